@@ -1,0 +1,438 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the MuJoCo routines the mink
+hot path calls.  Nothing under mink_amd/ may import this module.
+
+MuJoCo (pinned ``mujoco==3.2.6`` in the reference's mac_env.yml:153) is a
+third-party dependency that is absent from /root/reference and from this image,
+so the routines below restate its *published* kinematics algorithms from the
+documentation of ``mj_kinematics``, ``mj_comPos``, ``mj_jac``,
+``mj_jacSubtreeCom``, ``mj_integratePos``, ``mj_differentiatePos`` and the
+``mju_*`` quaternion helpers.  Call sites in the reference:
+mink/configuration.py:63-64,145,225,235; mink/lie/so3.py:83,113,150;
+mink/tasks/posture_task.py:107; mink/tasks/com_task.py:96;
+mink/limits/configuration_limit.py:100,110;
+mink/limits/collision_avoidance_limit.py:49,69,71,219.
+
+PARITY UNPINNED against MuJoCo itself: no MuJoCo binary or golden output exists
+here.  These functions are pinned by the reference's own oracle-free checks
+instead (task Jacobian == finite difference of task error through
+mj_integratePos, tests/test_jacobians.py:41-108; hinge-only integrate == q+v*dt,
+tests/test_configuration.py:85-100) and by hand-computed poses.
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
+GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX, GEOM_MESH = 0, 2, 3, 6, 7
+MINVAL = 1e-15
+MAXVAL = 1e10
+
+
+# ----------------------------------------------------------------- mju_* ----
+def mju_mulQuat(a, b):
+    """Hamilton product of two (w, x, y, z) quaternions."""
+    return np.array([
+        a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+        a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+        a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+        a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0],
+    ])
+
+
+def mju_quat2Mat(q):
+    """3x3 rotation matrix of a unit quaternion (no normalisation)."""
+    q00, q11, q22, q33 = q[0] * q[0], q[1] * q[1], q[2] * q[2], q[3] * q[3]
+    q01, q02, q03 = q[0] * q[1], q[0] * q[2], q[0] * q[3]
+    q12, q13, q23 = q[1] * q[2], q[1] * q[3], q[2] * q[3]
+    return np.array([
+        [q00 + q11 - q22 - q33, 2 * (q12 - q03), 2 * (q13 + q02)],
+        [2 * (q12 + q03), q00 - q11 + q22 - q33, 2 * (q23 - q01)],
+        [2 * (q13 - q02), 2 * (q23 + q01), q00 - q11 - q22 + q33],
+    ])
+
+
+def mju_normalize4(q):
+    n = math.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])
+    if n < MINVAL:
+        return np.array([1.0, 0.0, 0.0, 0.0])
+    return np.asarray(q, dtype=np.float64) / n
+
+
+def mju_normalize3(v):
+    """Returns (unit vector, norm); a vanishing vector maps to (1, 0, 0)."""
+    n = math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+    if n < MINVAL:
+        return np.array([1.0, 0.0, 0.0]), 0.0
+    return np.asarray(v, dtype=np.float64) / n, n
+
+
+def mju_mat2Quat(m):
+    """Quaternion of a rotation matrix (row-major 9-vector or 3x3); the sign of
+    w is not canonicalised."""
+    m = np.asarray(m, dtype=np.float64).reshape(9)
+    q = np.zeros(4)
+    if m[0] + m[4] + m[8] > 0:
+        q[0] = 0.5 * math.sqrt(1 + m[0] + m[4] + m[8])
+        q[1] = 0.25 * (m[7] - m[5]) / q[0]
+        q[2] = 0.25 * (m[2] - m[6]) / q[0]
+        q[3] = 0.25 * (m[3] - m[1]) / q[0]
+    elif m[0] > m[4] and m[0] > m[8]:
+        q[1] = 0.5 * math.sqrt(1 + m[0] - m[4] - m[8])
+        q[0] = 0.25 * (m[7] - m[5]) / q[1]
+        q[2] = 0.25 * (m[1] + m[3]) / q[1]
+        q[3] = 0.25 * (m[2] + m[6]) / q[1]
+    elif m[4] > m[8]:
+        q[2] = 0.5 * math.sqrt(1 - m[0] + m[4] - m[8])
+        q[0] = 0.25 * (m[2] - m[6]) / q[2]
+        q[1] = 0.25 * (m[1] + m[3]) / q[2]
+        q[3] = 0.25 * (m[5] + m[7]) / q[2]
+    else:
+        q[3] = 0.5 * math.sqrt(1 - m[0] - m[4] + m[8])
+        q[0] = 0.25 * (m[3] - m[1]) / q[3]
+        q[1] = 0.25 * (m[2] + m[6]) / q[3]
+        q[2] = 0.25 * (m[5] + m[7]) / q[3]
+    return mju_normalize4(q)
+
+
+def mju_axisAngle2Quat(axis, angle):
+    if angle == 0.0:
+        return np.array([1.0, 0.0, 0.0, 0.0])
+    s = math.sin(0.5 * angle)
+    return np.array([math.cos(0.5 * angle), s * axis[0], s * axis[1], s * axis[2]])
+
+
+def mju_rotVecQuat(v, q):
+    """Rotate vector ``v`` by unit quaternion ``q``."""
+    return mju_quat2Mat(q) @ np.asarray(v, dtype=np.float64)
+
+
+def mju_quatIntegrate(quat, omega, scale):
+    """quat <- normalize(quat) * axisangle(omega/|omega|, scale*|omega|); omega is
+    expressed in the rotating (body) frame."""
+    axis, n = mju_normalize3(omega)
+    qrot = mju_axisAngle2Quat(axis, scale * n)
+    return mju_mulQuat(mju_normalize4(quat), qrot)
+
+
+def mju_quat2Vel(q, dt):
+    axis, s = mju_normalize3(q[1:4])
+    speed = 2.0 * math.atan2(s, q[0])
+    if speed > math.pi:
+        speed -= 2.0 * math.pi
+    return axis * (speed / dt)
+
+
+def mju_subQuat(qa, qb):
+    """Rotation vector taking qb to qa, in qb's frame: quat2Vel(conj(qb)*qa)."""
+    conj = np.array([qb[0], -qb[1], -qb[2], -qb[3]])
+    return mju_quat2Vel(mju_mulQuat(conj, qa), 1.0)
+
+
+# ------------------------------------------------------------------ data ----
+class Data:
+    """Per-configuration kinematic state; field names mirror ``mujoco.MjData``."""
+
+    def __init__(self, model):
+        m = model
+        self.model = m
+        self.qpos = m.qpos0.copy()
+        self.xpos = np.zeros((m.nbody, 3))
+        self.xquat = np.tile([1.0, 0.0, 0.0, 0.0], (m.nbody, 1))
+        self.xmat = np.tile(np.eye(3).reshape(9), (m.nbody, 1))
+        self.xipos = np.zeros((m.nbody, 3))
+        self.xanchor = np.zeros((m.njnt, 3))
+        self.xaxis = np.zeros((m.njnt, 3))
+        self.site_xpos = np.zeros((m.nsite, 3))
+        self.site_xmat = np.zeros((m.nsite, 9))
+        self.geom_xpos = np.zeros((m.ngeom, 3))
+        self.geom_xmat = np.zeros((m.ngeom, 9))
+        self.subtree_com = np.zeros((m.nbody, 3))
+        nm = max(m.nmocap, 0)
+        self.mocap_pos = np.zeros((nm, 3))
+        self.mocap_quat = np.tile([1.0, 0.0, 0.0, 0.0], (nm, 1))
+        for b in range(m.nbody):
+            k = m.body_mocapid[b]
+            if k >= 0:
+                self.mocap_pos[k] = m.body_pos[b]
+                self.mocap_quat[k] = m.body_quat[b]
+
+
+# ----------------------------------------------------------- kinematics ----
+def mj_kinematics(m, d):
+    """Forward kinematics of every body, site and geom."""
+    d.xpos[0] = 0.0
+    d.xquat[0] = [1.0, 0.0, 0.0, 0.0]
+    d.xmat[0] = np.eye(3).reshape(9)
+    d.xipos[0] = 0.0
+    for b in range(1, m.nbody):
+        mid = m.body_mocapid[b]
+        jadr, jnum = m.body_jntadr[b], m.body_jntnum[b]
+        if mid >= 0:
+            xpos = d.mocap_pos[mid].copy()
+            xquat = mju_normalize4(d.mocap_quat[mid])
+        elif jnum == 1 and m.jnt_type[jadr] == JNT_FREE:
+            a = m.jnt_qposadr[jadr]
+            xpos = d.qpos[a:a + 3].copy()
+            xquat = mju_normalize4(d.qpos[a + 3:a + 7])
+            d.xanchor[jadr] = xpos
+            d.xaxis[jadr] = m.jnt_axis[jadr]
+        else:
+            p = m.body_parentid[b]
+            xpos = d.xmat[p].reshape(3, 3) @ m.body_pos[b] + d.xpos[p]
+            xquat = mju_mulQuat(d.xquat[p], m.body_quat[b])
+            for j in range(jadr, jadr + jnum):
+                a = m.jnt_qposadr[j]
+                jt = m.jnt_type[j]
+                xaxis = mju_rotVecQuat(m.jnt_axis[j], xquat)
+                xanchor = mju_rotVecQuat(m.jnt_pos[j], xquat) + xpos
+                d.xaxis[j] = xaxis
+                d.xanchor[j] = xanchor
+                if jt == JNT_SLIDE:
+                    xpos = xpos + xaxis * (d.qpos[a] - m.qpos0[a])
+                elif jt in (JNT_BALL, JNT_HINGE):
+                    if jt == JNT_BALL:
+                        qloc = mju_normalize4(d.qpos[a:a + 4])
+                    else:
+                        qloc = mju_axisAngle2Quat(m.jnt_axis[j], d.qpos[a] - m.qpos0[a])
+                    xquat = mju_mulQuat(xquat, qloc)
+                    xpos = xanchor - mju_rotVecQuat(m.jnt_pos[j], xquat)
+                else:
+                    raise ValueError("free joint must be the only joint of its body")
+        xquat = mju_normalize4(xquat)
+        d.xpos[b] = xpos
+        d.xquat[b] = xquat
+        xmat = mju_quat2Mat(xquat)
+        d.xmat[b] = xmat.reshape(9)
+        d.xipos[b] = xpos + xmat @ m.body_ipos[b]
+    for s in range(m.nsite):
+        b = m.site_bodyid[s]
+        d.site_xpos[s] = d.xmat[b].reshape(3, 3) @ m.site_pos[s] + d.xpos[b]
+        d.site_xmat[s] = mju_quat2Mat(mju_mulQuat(d.xquat[b], m.site_quat[s])).reshape(9)
+    for g in range(m.ngeom):
+        b = m.geom_bodyid[g]
+        d.geom_xpos[g] = d.xmat[b].reshape(3, 3) @ m.geom_pos[g] + d.xpos[b]
+        d.geom_xmat[g] = mju_quat2Mat(mju_mulQuat(d.xquat[b], m.geom_quat[g])).reshape(9)
+
+
+def subtree_mass(m):
+    tot = m.body_mass.astype(np.float64).copy()
+    for b in range(m.nbody - 1, 0, -1):
+        tot[m.body_parentid[b]] += tot[b]
+    return tot
+
+
+def mj_comPos(m, d):
+    """Subtree centres of mass (mass-weighted xipos accumulated child -> parent)."""
+    acc = d.xipos * m.body_mass[:, None]
+    for b in range(m.nbody - 1, 0, -1):
+        acc[m.body_parentid[b]] += acc[b]
+    tot = subtree_mass(m)
+    for b in range(m.nbody):
+        d.subtree_com[b] = acc[b] / tot[b] if tot[b] >= MINVAL else d.xipos[b]
+
+
+def mj_jac(m, d, point, body):
+    """World-aligned translational and rotational Jacobians (3 x nv each) of a
+    world-frame ``point`` rigidly attached to ``body``."""
+    jacp = np.zeros((3, m.nv))
+    jacr = np.zeros((3, m.nv))
+    while body and m.body_dofnum[body] == 0:
+        body = m.body_parentid[body]
+    if body == 0:
+        return jacp, jacr
+    i = m.body_dofadr[body] + m.body_dofnum[body] - 1
+    point = np.asarray(point, dtype=np.float64)
+    while i >= 0:
+        j = m.dof_jntid[i]
+        jt = m.jnt_type[j]
+        k = i - m.jnt_dofadr[j]
+        if jt == JNT_SLIDE:
+            jacp[:, i] = d.xaxis[j]
+        elif jt == JNT_HINGE:
+            jacr[:, i] = d.xaxis[j]
+            jacp[:, i] = np.cross(d.xaxis[j], point - d.xanchor[j])
+        elif jt == JNT_FREE and k < 3:
+            jacp[k, i] = 1.0
+        else:
+            # rotational dofs of free / ball joints act about the body's own axes
+            kk = k - 3 if jt == JNT_FREE else k
+            axis = d.xmat[m.jnt_bodyid[j]].reshape(3, 3)[:, kk]
+            jacr[:, i] = axis
+            jacp[:, i] = np.cross(axis, point - d.xanchor[j])
+        i = m.dof_parentid[i]
+    return jacp, jacr
+
+
+def mj_jacBody(m, d, body):
+    return mj_jac(m, d, d.xpos[body], body)
+
+
+def mj_jacSite(m, d, site):
+    return mj_jac(m, d, d.site_xpos[site], m.site_bodyid[site])
+
+
+def mj_jacGeom(m, d, geom):
+    return mj_jac(m, d, d.geom_xpos[geom], m.geom_bodyid[geom])
+
+
+def mj_jacSubtreeCom(m, d, body):
+    """Translational Jacobian of the centre of mass of the subtree rooted at body."""
+    jac = np.zeros((3, m.nv))
+    tot = 0.0
+    for b in range(body, m.nbody):
+        # b is in the subtree iff walking up its parents reaches `body`
+        p = b
+        while p > body:
+            p = m.body_parentid[p]
+        if p != body:
+            continue
+        jp, _ = mj_jac(m, d, d.xipos[b], b)
+        jac += m.body_mass[b] * jp
+        tot += m.body_mass[b]
+    return jac / tot if tot >= MINVAL else jac
+
+
+def mj_integratePos(m, qpos, qvel, dt):
+    """In-place qpos <- qpos (+) dt*qvel on the configuration manifold."""
+    for j in range(m.njnt):
+        a, v = m.jnt_qposadr[j], m.jnt_dofadr[j]
+        jt = m.jnt_type[j]
+        if jt == JNT_FREE:
+            qpos[a:a + 3] += dt * qvel[v:v + 3]
+            qpos[a + 3:a + 7] = mju_quatIntegrate(qpos[a + 3:a + 7], qvel[v + 3:v + 6], dt)
+        elif jt == JNT_BALL:
+            qpos[a:a + 4] = mju_quatIntegrate(qpos[a:a + 4], qvel[v:v + 3], dt)
+        else:
+            qpos[a] += dt * qvel[v]
+
+
+def mj_differentiatePos(m, dt, qpos1, qpos2):
+    """Returns qvel = (qpos2 (-) qpos1) / dt in tangent coordinates."""
+    qvel = np.zeros(m.nv)
+    for j in range(m.njnt):
+        a, v = m.jnt_qposadr[j], m.jnt_dofadr[j]
+        jt = m.jnt_type[j]
+        if jt == JNT_FREE:
+            qvel[v:v + 3] = (qpos2[a:a + 3] - qpos1[a:a + 3]) / dt
+            qvel[v + 3:v + 6] = mju_subQuat(qpos2[a + 3:a + 7], qpos1[a + 3:a + 7]) / dt
+        elif jt == JNT_BALL:
+            qvel[v:v + 3] = mju_subQuat(qpos2[a:a + 4], qpos1[a:a + 4]) / dt
+        else:
+            qvel[v] = (qpos2[a] - qpos1[a]) / dt
+    return qvel
+
+
+# --------------------------------------------------------- geom distance ----
+def _box_support_points(center, rot, half):
+    signs = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64)
+    return center + (signs * half) @ rot.T
+
+
+def _closest_box_box(c1, r1, h1, c2, r2, h2):
+    """Closest points between two separated oriented boxes, by GJK on the
+    Minkowski difference with an exact closest-point-on-simplex sub-solver.
+    Returns (dist, p1, p2); dist <= 0 reports overlap with p1 = p2 = midpoint."""
+
+    def support(d):
+        s1 = c1 + r1 @ (np.sign(r1.T @ d + 1e-300) * h1)
+        s2 = c2 + r2 @ (np.sign(r2.T @ (-d) + 1e-300) * h2)
+        return s1 - s2, s1, s2
+
+    def closest_on_simplex(W):
+        # Enumerate sub-simplices (<= 4 points): exact for these tiny sets.
+        best = None
+        n = len(W)
+        import itertools
+        for k in range(1, n + 1):
+            for idx in itertools.combinations(range(n), k):
+                P = np.array([W[i] for i in idx])
+                if k == 1:
+                    lam = np.array([1.0])
+                else:
+                    A = (P[1:] - P[0]).T
+                    try:
+                        t = np.linalg.solve(A.T @ A, -A.T @ P[0])
+                    except np.linalg.LinAlgError:
+                        continue
+                    lam = np.concatenate([[1.0 - t.sum()], t])
+                if np.any(lam < -1e-14):
+                    continue
+                v = lam @ P
+                dd = float(v @ v)
+                if best is None or dd < best[0] - 1e-30:
+                    best = (dd, idx, lam)
+        return best
+
+    d = c1 - c2
+    if float(d @ d) < 1e-30:
+        d = np.array([1.0, 0.0, 0.0])
+    w, a, b = support(-d)
+    W, A, B = [w], [a], [b]
+    v = w
+    for _ in range(64):
+        vv = float(v @ v)
+        if vv < 1e-24:
+            mid = 0.5 * (sum(A) / len(A) + sum(B) / len(B))
+            return 0.0, mid, mid
+        w, a, b = support(-v)
+        if vv - float(v @ w) <= 1e-14 * vv:
+            break
+        W.append(w); A.append(a); B.append(b)
+        dd, idx, lam = closest_on_simplex(W)
+        W = [W[i] for i in idx]; A = [A[i] for i in idx]; B = [B[i] for i in idx]
+        v = lam @ np.array(W)
+        lam_keep = lam
+    else:
+        pass
+    dd, idx, lam = closest_on_simplex(W)
+    p1 = lam @ np.array([A[i] for i in idx])
+    p2 = lam @ np.array([B[i] for i in idx])
+    return math.sqrt(dd), p1, p2
+
+
+def mj_geomDistance(m, d, g1, g2, distmax):
+    """Smallest signed distance between two primitive geoms, and the segment
+    (fromto) joining the closest points, or (distmax, zeros) when farther than
+    distmax.  Supported pairs: plane-box, box-box (separated), sphere-*.
+    PARITY UNPINNED: MuJoCo's box-box routine is not restated; the Euclidean
+    closest-point distance is used instead."""
+    t1, t2 = m.geom_type[g1], m.geom_type[g2]
+    fromto = np.zeros(6)
+    swap = False
+    if t1 > t2:
+        g1, g2, t1, t2 = g2, g1, t2, t1
+        swap = True
+    c1, c2 = d.geom_xpos[g1], d.geom_xpos[g2]
+    r1, r2 = d.geom_xmat[g1].reshape(3, 3), d.geom_xmat[g2].reshape(3, 3)
+    s1, s2 = m.geom_size[g1], m.geom_size[g2]
+    if t1 == GEOM_PLANE and t2 == GEOM_BOX:
+        n = r1[:, 2]
+        corners = _box_support_points(c2, r2, s2)
+        depth = (corners - c1) @ n
+        k = int(np.argmin(depth))
+        dist = float(depth[k])
+        p2 = corners[k]
+        p1 = p2 - dist * n
+    elif t1 == GEOM_PLANE and t2 == GEOM_SPHERE:
+        n = r1[:, 2]
+        dist = float((c2 - c1) @ n) - s2[0]
+        p2 = c2 - s2[0] * n
+        p1 = p2 - dist * n
+    elif t1 == GEOM_SPHERE and t2 == GEOM_SPHERE:
+        axis, nrm = mju_normalize3(c2 - c1)
+        dist = nrm - s1[0] - s2[0]
+        p1 = c1 + s1[0] * axis
+        p2 = c2 - s2[0] * axis
+    elif t1 == GEOM_BOX and t2 == GEOM_BOX:
+        dist, p1, p2 = _closest_box_box(c1, r1, s1, c2, r2, s2)
+    else:
+        raise NotImplementedError(f"geom pair types ({t1}, {t2})")
+    if dist >= distmax:
+        return distmax, fromto
+    if swap:
+        p1, p2 = p2, p1
+    fromto[:3], fromto[3:] = p1, p2
+    return dist, fromto

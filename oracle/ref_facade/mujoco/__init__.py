@@ -1,0 +1,164 @@
+"""TEST-TIME TOOL, used only by tests/golden/make_golden.py in the build container.
+
+A ``mujoco``-shaped facade over oracle/mjlite.py so that the *unmodified*
+reference package (/root/reference/mink) can be imported and executed to
+capture golden vectors.  What such vectors pin is the reference's own Python
+(mink/lie, mink/tasks, mink/limits, mink/configuration.py, mink/solve_ik.py);
+the kinematics underneath are this repository's restatement, not MuJoCo.
+Signatures follow the MuJoCo Python bindings (outputs written in place).
+"""
+import enum
+import os
+import sys
+
+import numpy as np
+
+_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from oracle import mjlite as _mj  # noqa: E402
+from mink_amd import mjcf as _mjcf  # noqa: E402
+
+mjMAXVAL = 1e10
+mjMINVAL = 1e-15
+
+
+class mjtObj(enum.IntEnum):
+    mjOBJ_BODY = 1
+    mjOBJ_JOINT = 3
+    mjOBJ_GEOM = 5
+    mjOBJ_SITE = 6
+    mjOBJ_KEY = 23
+
+
+class mjtJoint(enum.IntEnum):
+    mjJNT_FREE = 0
+    mjJNT_BALL = 1
+    mjJNT_SLIDE = 2
+    mjJNT_HINGE = 3
+
+
+class _Named:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class MjModel:
+    def __init__(self, table):
+        self._t = table
+
+    @classmethod
+    def from_xml_path(cls, path):
+        return cls(_mjcf.load_mjcf(path))
+
+    def __getattr__(self, k):
+        return getattr(self._t, k)
+
+    def _lookup(self, names, key):
+        return names.index(key) if isinstance(key, str) else int(key)
+
+    def body(self, key):
+        i = self._lookup(self._t.body_names, key)
+        return _Named(id=i, name=self._t.body_names[i], mocapid=np.array([self._t.body_mocapid[i]]))
+
+    def joint(self, key):
+        i = self._lookup(self._t.jnt_names, key)
+        return _Named(id=i, name=self._t.jnt_names[i])
+
+    def geom(self, key):
+        i = self._lookup(self._t.geom_names, key)
+        return _Named(id=i, name=self._t.geom_names[i])
+
+    def site(self, key):
+        i = self._lookup(self._t.site_names, key)
+        return _Named(id=i, name=self._t.site_names[i])
+
+    def key(self, key):
+        i = self._lookup(self._t.key_names, key)
+        return _Named(id=i, name=self._t.key_names[i])
+
+
+class MjData:
+    def __init__(self, model):
+        object.__setattr__(self, "_d", _mj.Data(model._t))
+
+    def __getattr__(self, k):
+        return getattr(self._d, k)
+
+    def __setattr__(self, k, v):
+        if k == "qpos":
+            self._d.qpos[:] = v
+        else:
+            setattr(self._d, k, v)
+
+
+def mj_name2id(m, objtype, name):
+    t = m._t
+    return {mjtObj.mjOBJ_BODY: t.body_id, mjtObj.mjOBJ_GEOM: t.geom_id, mjtObj.mjOBJ_SITE: t.site_id,
+            mjtObj.mjOBJ_KEY: t.key_id, mjtObj.mjOBJ_JOINT: t.joint_id}[objtype](name)
+
+
+def mj_kinematics(m, d):
+    _mj.mj_kinematics(m._t, d._d)
+
+
+def mj_comPos(m, d):
+    _mj.mj_comPos(m._t, d._d)
+
+
+def mj_jac(m, d, jacp, jacr, point, body):
+    jp, jr = _mj.mj_jac(m._t, d._d, point, body)
+    if jacp is not None:
+        jacp[:] = jp
+    if jacr is not None:
+        jacr[:] = jr
+
+
+def mj_jacBody(m, d, jacp, jacr, i):
+    mj_jac(m, d, jacp, jacr, d._d.xpos[i], i)
+
+
+def mj_jacSite(m, d, jacp, jacr, i):
+    mj_jac(m, d, jacp, jacr, d._d.site_xpos[i], m._t.site_bodyid[i])
+
+
+def mj_jacGeom(m, d, jacp, jacr, i):
+    mj_jac(m, d, jacp, jacr, d._d.geom_xpos[i], m._t.geom_bodyid[i])
+
+
+def mj_jacSubtreeCom(m, d, jac, body):
+    jac[:] = _mj.mj_jacSubtreeCom(m._t, d._d, body)
+
+
+def mj_integratePos(m, qpos, qvel, dt):
+    _mj.mj_integratePos(m._t, qpos, np.asarray(qvel, dtype=np.float64), dt)
+
+
+def mj_differentiatePos(m, qvel, dt, qpos1, qpos2):
+    qvel[:] = _mj.mj_differentiatePos(m._t, dt, qpos1, qpos2)
+
+
+def mj_geomDistance(m, d, g1, g2, distmax, fromto):
+    dist, ft = _mj.mj_geomDistance(m._t, d._d, g1, g2, distmax)
+    if fromto is not None:
+        fromto[:] = ft
+    return dist
+
+
+def mju_mat2Quat(quat, mat):
+    quat[:] = _mj.mju_mat2Quat(mat)
+
+
+def mju_quat2Mat(mat, quat):
+    mat[:] = _mj.mju_quat2Mat(quat).reshape(9)
+
+
+def mju_mulQuat(res, a, b):
+    res[:] = _mj.mju_mulQuat(a, b)
+
+
+def mju_normalize3(vec):
+    v, n = _mj.mju_normalize3(vec)
+    vec[:] = v
+    return n
