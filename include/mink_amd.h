@@ -1,0 +1,194 @@
+/*
+ * mink_amd -- C ABI of the MI355X batched differential-IK engine.
+ *
+ * The reference (priyasundaresan/mink, a vendored copy of mink 0.0.5) is pure
+ * Python on top of MuJoCo and qpsolvers; it has no FFI of its own.  Each entry
+ * point below replaces one Python-level interface of the reference's hot path
+ * (cited per function) with a batched device routine: every array gains a
+ * leading batch dimension B and lives in GPU memory owned by the caller.
+ *
+ * Conventions
+ *   - all pointers named d_* are DEVICE pointers (hipMalloc / torch ROCm tensors),
+ *     row-major, contiguous, 8-byte aligned; everything else is host memory that
+ *     is only read during the call;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
+ *     asynchronous on it and never synchronise;
+ *   - functions return MK_OK or a negative error code, never throw; the message of
+ *     the last failure on the calling thread is available from mk_last_error();
+ *   - per-problem solver outcome goes to an int32 status array:
+ *       0 solved, 1 iteration limit, 2 infeasible constraints, 3 non-finite input.
+ *   - quaternions are (w, x, y, z); poses are (qw, qx, qy, qz, x, y, z) like
+ *     mink.SE3.wxyz_xyz (mink/lie/se3.py:20-24); twists are (v; omega).
+ */
+#ifndef MINK_AMD_H_
+#define MINK_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MK_OK 0
+#define MK_ERR_INVALID (-1)     /* bad argument / inconsistent descriptor */
+#define MK_ERR_UNSUPPORTED (-2) /* valid request outside what the kernels implement */
+#define MK_ERR_HIP (-3)         /* a HIP runtime call failed */
+
+/* joint types: MuJoCo mjtJoint values, as assumed by mink/constants.py:27-34 */
+enum { MK_JNT_FREE = 0, MK_JNT_BALL = 1, MK_JNT_SLIDE = 2, MK_JNT_HINGE = 3 };
+/* frame types: mink/constants.py:3 SUPPORTED_FRAMES */
+enum { MK_FRAME_BODY = 0, MK_FRAME_GEOM = 1, MK_FRAME_SITE = 2 };
+/* task types: mink/tasks/{frame_task,relative_frame_task,posture_task,com_task}.py;
+ * DampingTask (mink/tasks/damping_task.py) is a posture task with gain 0 and
+ * target qpos0. */
+enum { MK_TASK_FRAME = 0, MK_TASK_RELATIVE_FRAME = 1, MK_TASK_POSTURE = 2, MK_TASK_COM = 3 };
+/* limit types: mink/limits/{configuration_limit,velocity_limit,collision_avoidance_limit}.py */
+enum { MK_LIMIT_CONFIGURATION = 0, MK_LIMIT_VELOCITY = 1, MK_LIMIT_COLLISION = 2 };
+
+/* Flat kinematic tree; field names follow mujoco.MjModel, which is what the
+ * reference reads (mink/configuration.py:86-97, mink/limits/configuration_limit.py:41-56). */
+typedef struct mk_model_desc {
+  int32_t nq, nv, nbody, njnt, ngeom, nsite;
+  const int32_t* body_parentid; /* [nbody] */
+  const int32_t* body_jntadr;   /* [nbody] first joint or -1 */
+  const int32_t* body_jntnum;   /* [nbody] */
+  const int32_t* body_mocapid;  /* [nbody] -1 if not mocap */
+  const double* body_pos;       /* [nbody*3] */
+  const double* body_quat;      /* [nbody*4] normalised */
+  const double* body_mass;      /* [nbody] */
+  const double* body_ipos;      /* [nbody*3] */
+  const int32_t* jnt_type;      /* [njnt] */
+  const int32_t* jnt_qposadr;   /* [njnt] */
+  const int32_t* jnt_dofadr;    /* [njnt] */
+  const int32_t* jnt_bodyid;    /* [njnt] */
+  const int32_t* jnt_limited;   /* [njnt] 0/1 */
+  const double* jnt_pos;        /* [njnt*3] */
+  const double* jnt_axis;       /* [njnt*3] */
+  const double* jnt_range;      /* [njnt*2] */
+  const double* qpos0;          /* [nq] */
+  const int32_t* dof_parentid;  /* [nv] */
+  const int32_t* dof_jntid;     /* [nv] */
+  const int32_t* site_bodyid;   /* [nsite] */
+  const double* site_pos;       /* [nsite*3] */
+  const double* site_quat;      /* [nsite*4] */
+  const int32_t* geom_bodyid;   /* [ngeom] */
+  const int32_t* geom_type;     /* [ngeom] MuJoCo mjtGeom */
+  const double* geom_size;      /* [ngeom*3] */
+  const double* geom_pos;       /* [ngeom*3] */
+  const double* geom_quat;      /* [ngeom*4] */
+} mk_model_desc;
+
+/* One kinematic task.  Pose targets of frame tasks are per-problem inputs of the
+ * solve calls; everything here is shared by the whole batch. */
+typedef struct mk_task_desc {
+  int32_t type;            /* MK_TASK_* */
+  int32_t frame_type;      /* MK_FRAME_* (frame / relative frame) */
+  int32_t frame_id;
+  int32_t root_type;       /* relative frame only */
+  int32_t root_id;
+  int32_t ncost;           /* 6 (frame tasks), nv (posture), 3 (com) */
+  double gain;             /* task gain alpha, mink/tasks/task.py:71 */
+  double lm_damping;       /* mink/tasks/task.py:74 */
+  const double* cost;      /* [ncost] already broadcast */
+  const double* target_q;  /* posture: [nq] */
+} mk_task_desc;
+
+typedef struct mk_limit_desc {
+  int32_t type;                      /* MK_LIMIT_* */
+  int32_t n;                         /* velocity: number of dofs; collision: number of pairs */
+  double gain;                       /* configuration (default 0.95) / collision (0.85) */
+  double min_distance_from_limits;   /* configuration */
+  const int32_t* index;              /* velocity: [n] dof ids; collision: [2n] geom id pairs */
+  const double* vmax;                /* velocity: [n] */
+  double minimum_distance_from_collisions; /* collision */
+  double collision_detection_distance;     /* collision */
+  double bound_relaxation;                  /* collision */
+} mk_limit_desc;
+
+typedef struct mk_model mk_model;
+typedef struct mk_problem mk_problem;
+
+typedef struct mk_problem_info {
+  int32_t nq, nv;
+  int32_t target_stride; /* doubles of per-problem target data (7 per frame / relative
+                            frame task, 3 per com task, in task order) */
+  int32_t n_rows;        /* rows of the stacked inequality matrix G (mink/solve_ik.py:40) */
+  int32_t fused;         /* 1: the single-kernel structured path serves this problem */
+  int32_t n_chain;       /* dofs with dense coupling in the fused path */
+} mk_problem_info;
+
+/* Replaces mujoco.MjModel.from_xml_path + mujoco.MjData construction
+ * (interactive_scripts/teleop_mouse.py:29-30, mink/configuration.py:49-51): copies
+ * the tree to the device that is current at the time of the call. */
+int mk_model_create(const mk_model_desc* desc, mk_model** out);
+void mk_model_destroy(mk_model* model);
+
+/* Replaces constructing the task and limit objects handed to mink.solve_ik
+ * (interactive_scripts/teleop_mouse.py:46-69; mink/solve_ik.py:28-29 builds the
+ * default ConfigurationLimit on every call, here it is built once). nlimit = 0
+ * means unconstrained (limits=[]). */
+int mk_problem_create(const mk_model* model, const mk_task_desc* tasks, int32_t ntask,
+                      const mk_limit_desc* limits, int32_t nlimit, mk_problem** out);
+void mk_problem_destroy(mk_problem* problem);
+int mk_problem_get_info(const mk_problem* problem, mk_problem_info* info);
+
+/* mink.solve_ik without the limit check (mink/solve_ik.py:100-105): build the QP
+ * of every problem, solve it exactly and return v = dq / dt.
+ *   d_q [B, nq], d_targets [B, target_stride], d_v [B, nv], d_status [B]. */
+int mk_solve_ik_batch(const mk_problem* problem, const double* d_q, const double* d_targets,
+                      double dt, double damping, int32_t B, double* d_v, int32_t* d_status,
+                      void* stream);
+
+/* The callers' loop (interactive_scripts/teleop_mouse.py:105-121,
+ * envs/mj_env.py:266-276): up to max_iters x (solve_ik -> integrate_inplace ->
+ * frame-task error), leaving the loop of a problem once its first frame task has
+ * |e[:3]| <= pos_tol and |e[3:]| <= ori_tol (pass negative tolerances to run
+ * exactly max_iters solves).  d_q is updated in place; optional outputs (may be
+ * NULL): d_v last velocity [B, nv], d_iters solves executed [B], d_err final
+ * frame-task error [B, 6]. */
+int mk_solve_ik_iterate_batch(const mk_problem* problem, double* d_q, const double* d_targets,
+                              double dt, double damping, int32_t B, int32_t max_iters,
+                              double pos_tol, double ori_tol, double* d_v, int32_t* d_iters,
+                              double* d_err, int32_t* d_status, void* stream);
+
+/* Configuration.integrate_inplace minus the FK refresh (mink/configuration.py:228-236,
+ * i.e. mujoco.mj_integratePos): d_q [B, nq] <- d_q (+) dt * d_v [B, nv]. */
+int mk_integrate_batch(const mk_model* model, double* d_q, const double* d_v, double dt,
+                       int32_t B, void* stream);
+
+/* Configuration.get_transform_frame_to_world (mink/configuration.py:157-185):
+ * d_pose [B, 7] of frame (frame_type, frame_id) at d_q [B, nq]. */
+int mk_fk_batch(const mk_model* model, const double* d_q, int32_t B, int32_t frame_type,
+                int32_t frame_id, double* d_pose, void* stream);
+
+/* Configuration.get_frame_jacobian (mink/configuration.py:112-155): body-frame
+ * Jacobian d_jac [B, 6, nv], rows (linear; angular). */
+int mk_frame_jacobian_batch(const mk_model* model, const double* d_q, int32_t B,
+                            int32_t frame_type, int32_t frame_id, double* d_jac, void* stream);
+
+/* Configuration.check_limits (mink/configuration.py:77-110): d_first_violation [B]
+ * receives the id of the first joint outside [lower - tol, upper + tol], or -1. */
+int mk_check_limits_batch(const mk_model* model, const double* d_q, double tol, int32_t B,
+                          int32_t* d_first_violation, void* stream);
+
+/* mink.build_ik (mink/solve_ik.py:43-65): dense d_P [B, nv, nv], d_c [B, nv],
+ * d_G [B, n_rows, nv], d_h [B, n_rows] (G/h may be NULL when n_rows == 0).
+ * Rows of inactive collision pairs are zero with h = +inf, as in the reference. */
+int mk_build_qp_batch(const mk_problem* problem, const double* d_q, const double* d_targets,
+                      double dt, double damping, int32_t B, double* d_P, double* d_c,
+                      double* d_G, double* d_h, void* stream);
+
+/* qpsolvers.solve_problem(Problem(P, q, G, h), solver) (mink/solve_ik.py:101):
+ * min 1/2 x'Px + c'x s.t. Gx <= h for B independent dense problems, P positive
+ * definite; n <= 64, m <= 256.  d_x [B, n]. */
+int mk_qp_solve_batch(const double* d_P, const double* d_c, const double* d_G, const double* d_h,
+                      int32_t n, int32_t m, int32_t B, double* d_x, int32_t* d_status,
+                      void* stream);
+
+/* Message of the last error on the calling thread ("" if none). */
+const char* mk_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINK_AMD_H_ */

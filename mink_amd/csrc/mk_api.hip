@@ -1,0 +1,569 @@
+// Host side of the C ABI declared in include/mink_amd.h: opaque handles, validation,
+// flattening of model / task / limit descriptors into the device descriptors the
+// kernels read, and kernel dispatch.  No device memory is allocated by the solve
+// calls themselves; handles own the (small) descriptor buffers.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mink_amd.h"
+#include "mk_device.h"
+#include "mk_generic.h"
+
+// ---- launchers implemented in mk_fused.hip ----
+hipError_t mk_fused_launch_step(int nc, const MkFusedDesc* d_desc, int nq, const double* q, const double* targets,
+                                int target_stride, double dt, double damping, int B, double* v, int32_t* status,
+                                hipStream_t stream);
+hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, double* q, const double* targets,
+                                   int target_stride, double dt, double damping, int B, int max_iters,
+                                   double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
+                                   int32_t* status, hipStream_t stream);
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define MK_HIP(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) return fail(MK_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+template <typename T>
+std::vector<T> copy_in(const T* p, size_t n) {
+  return p ? std::vector<T>(p, p + n) : std::vector<T>(n, T());
+}
+
+struct HostModel {
+  int nq, nv, nbody, njnt, ngeom, nsite;
+  std::vector<int32_t> body_parentid, body_jntadr, body_jntnum, body_mocapid;
+  std::vector<double> body_pos, body_quat, body_mass, body_ipos;
+  std::vector<int32_t> jnt_type, jnt_qposadr, jnt_dofadr, jnt_bodyid, jnt_limited;
+  std::vector<double> jnt_pos, jnt_axis, jnt_range, qpos0;
+  std::vector<int32_t> dof_parentid, dof_jntid;
+  std::vector<int32_t> site_bodyid;
+  std::vector<double> site_pos, site_quat;
+  std::vector<int32_t> geom_bodyid, geom_type;
+  std::vector<double> geom_size, geom_pos, geom_quat;
+};
+
+void hq_mul(const double* a, const double* b, double* r) {
+  double t[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+                 a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                 a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+                 a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]};
+  memcpy(r, t, sizeof(t));
+}
+void hq_normalize(double* q) {
+  double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < 1e-15) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  for (int i = 0; i < 4; ++i) q[i] /= n;
+}
+void hq_rotate(const double* q, const double* v, double* r) {
+  double q00 = q[0] * q[0], q11 = q[1] * q[1], q22 = q[2] * q[2], q33 = q[3] * q[3];
+  double q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
+  double q12 = q[1] * q[2], q13 = q[1] * q[3], q23 = q[2] * q[3];
+  double m[9] = {q00 + q11 - q22 - q33, 2 * (q12 - q03), 2 * (q13 + q02),
+                 2 * (q12 + q03), q00 - q11 + q22 - q33, 2 * (q23 - q01),
+                 2 * (q13 - q02), 2 * (q23 + q01), q00 - q11 - q22 + q33};
+  double t[3] = {m[0] * v[0] + m[1] * v[1] + m[2] * v[2], m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
+                 m[6] * v[0] + m[7] * v[1] + m[8] * v[2]};
+  memcpy(r, t, sizeof(t));
+}
+
+// pose <- pose o (pos, quat)
+void compose(double* ppos, double* pquat, const double* pos, const double* quat) {
+  double r[3];
+  hq_rotate(pquat, pos, r);
+  for (int i = 0; i < 3; ++i) ppos[i] += r[i];
+  hq_mul(pquat, quat, pquat);
+  hq_normalize(pquat);
+}
+
+}  // namespace
+
+struct mk_model {
+  HostModel h;
+  MkDevModel dev;          // device pointers (owned)
+  std::vector<void*> allocs;
+  int device;
+};
+
+struct mk_problem {
+  const mk_model* model;
+  mk_problem_info info;
+  bool fused;
+  int nc_kernel;            // template size used by the fused kernels
+  MkFusedDesc* d_fused;     // device copy
+  MkFusedDesc h_fused;
+  MkGenericProblem gen;     // generic (dense) path description, device pointers owned below
+  std::vector<void*> allocs;
+};
+
+namespace {
+
+template <typename T>
+int upload(std::vector<void*>& allocs, const std::vector<T>& v, const T** out) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  MK_HIP(hipMalloc(&p, bytes));
+  allocs.push_back(p);
+  if (!v.empty()) MK_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = static_cast<const T*>(p);
+  return MK_OK;
+}
+
+int frame_body_and_local(const HostModel& m, int frame_type, int frame_id, int* body, double* pos, double* quat) {
+  pos[0] = pos[1] = pos[2] = 0.0;
+  quat[0] = 1.0; quat[1] = quat[2] = quat[3] = 0.0;
+  if (frame_type == MK_FRAME_BODY) {
+    if (frame_id < 0 || frame_id >= m.nbody) return fail(MK_ERR_INVALID, "body id %d out of range", frame_id);
+    *body = frame_id;
+  } else if (frame_type == MK_FRAME_SITE) {
+    if (frame_id < 0 || frame_id >= m.nsite) return fail(MK_ERR_INVALID, "site id %d out of range", frame_id);
+    *body = m.site_bodyid[frame_id];
+    memcpy(pos, &m.site_pos[3 * frame_id], 3 * sizeof(double));
+    memcpy(quat, &m.site_quat[4 * frame_id], 4 * sizeof(double));
+  } else if (frame_type == MK_FRAME_GEOM) {
+    if (frame_id < 0 || frame_id >= m.ngeom) return fail(MK_ERR_INVALID, "geom id %d out of range", frame_id);
+    *body = m.geom_bodyid[frame_id];
+    memcpy(pos, &m.geom_pos[3 * frame_id], 3 * sizeof(double));
+    memcpy(quat, &m.geom_quat[4 * frame_id], 4 * sizeof(double));
+  } else {
+    return fail(MK_ERR_INVALID, "unknown frame type %d", frame_type);
+  }
+  return MK_OK;
+}
+
+const int kFusedSizes[] = {4, 6, 7, 8, 10, 12};
+
+// Tries to express the problem in the structured form the fused kernels solve.
+// Returns false (with `why`) when the generic dense path is needed instead.
+bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const mk_limit_desc* limits, int nlimit,
+                 MkFusedDesc& D, int* nc_kernel, std::string& why) {
+  memset(&D, 0, sizeof(D));
+  if (m.nv > MK_MAX_NV || m.nq > MK_MAX_NQ) { why = "model too large"; return false; }
+  int frame_task = -1, nposture = 0, off = 0, target_off = 0;
+  for (int t = 0; t < ntask; ++t) {
+    if (tasks[t].type == MK_TASK_FRAME) {
+      if (frame_task >= 0) { why = "more than one frame task"; return false; }
+      frame_task = t;
+      target_off = off;
+      off += 7;
+    } else if (tasks[t].type == MK_TASK_POSTURE) {
+      if (++nposture > MK_MAX_POSTURE) { why = "too many posture tasks"; return false; }
+    } else {
+      why = "task type needs the dense path";
+      return false;
+    }
+  }
+  if (frame_task < 0) { why = "no frame task"; return false; }
+  for (int l = 0; l < nlimit; ++l)
+    if (limits[l].type == MK_LIMIT_COLLISION) { why = "collision limit adds general rows"; return false; }
+  for (int j = 0; j < m.njnt; ++j)
+    if (m.jnt_type[j] == MK_JNT_BALL) { why = "ball joint"; return false; }
+
+  D.nq = m.nq;
+  D.nv = m.nv;
+  D.target_off = target_off;
+  // dof table
+  for (int j = 0; j < m.njnt; ++j) {
+    const int a = m.jnt_dofadr[j], qa = m.jnt_qposadr[j];
+    if (m.jnt_type[j] == MK_JNT_FREE) {
+      if (D.nfree >= 8) { why = "too many free joints"; return false; }
+      D.free_qadr[D.nfree++] = qa;
+      for (int k = 0; k < 6; ++k) {
+        D.dof[a + k].qadr = qa + (k < 3 ? k : 3);
+        D.dof[a + k].kind = k < 3 ? MK_DOF_FREE_LIN : MK_DOF_FREE_ROT;
+        D.dof[a + k].slot = -1;
+      }
+    } else {
+      D.dof[a].qadr = qa;
+      D.dof[a].kind = MK_DOF_SCALAR;
+      D.dof[a].slot = -1;
+    }
+  }
+  // chain of the frame task
+  const mk_task_desc& ft = tasks[frame_task];
+  int body;
+  double lpos[3], lquat[4];
+  if (frame_body_and_local(m, ft.frame_type, ft.frame_id, &body, lpos, lquat) != MK_OK) { why = g_last_error; return false; }
+  std::vector<int> path;
+  for (int b = body; b != 0; b = m.body_parentid[b]) path.insert(path.begin(), b);
+  double ppos[3] = {0, 0, 0}, pquat[4] = {1, 0, 0, 0};
+  int nc = 0;
+  for (int b : path) {
+    if (m.body_mocapid[b] >= 0) { why = "frame attached to a mocap body"; return false; }
+    compose(ppos, pquat, &m.body_pos[3 * b], &m.body_quat[4 * b]);
+    const int jn = m.body_jntnum[b], ja = m.body_jntadr[b];
+    for (int j = ja; j < ja + jn; ++j) {
+      const int jt = m.jnt_type[j];
+      if (jt != MK_JNT_HINGE && jt != MK_JNT_SLIDE) { why = "free/ball joint on the task chain"; return false; }
+      if (nc >= MK_MAX_CHAIN) { why = "task chain longer than the fused kernels support"; return false; }
+      MkSeg& s = D.seg[nc];
+      s.type = jt;
+      s.qadr = m.jnt_qposadr[j];
+      s.dof = m.jnt_dofadr[j];
+      s.qpos0 = m.qpos0[s.qadr];
+      memcpy(s.jpos, &m.jnt_pos[3 * j], sizeof(s.jpos));
+      memcpy(s.axis, &m.jnt_axis[3 * j], sizeof(s.axis));
+      s.flags = 0;
+      if (j == ja) {
+        s.flags |= MK_SEG_HAS_PRE;
+        memcpy(s.pre_pos, ppos, sizeof(ppos));
+        memcpy(s.pre_quat, pquat, sizeof(pquat));
+        ppos[0] = ppos[1] = ppos[2] = 0.0;
+        pquat[0] = 1.0; pquat[1] = pquat[2] = pquat[3] = 0.0;
+      } else {
+        s.pre_quat[0] = 1.0;
+      }
+      if (j == ja + jn - 1) s.flags |= MK_SEG_END_BODY;
+      if (s.jpos[0] != 0.0 || s.jpos[1] != 0.0 || s.jpos[2] != 0.0) s.flags |= MK_SEG_HAS_JPOS;
+      if (s.axis[0] == 0.0 && s.axis[1] == 0.0 && s.axis[2] == 1.0) s.flags |= MK_SEG_AXIS_Z;
+      D.dof[s.dof].slot = nc;
+      ++nc;
+    }
+  }
+  if (nc == 0) { why = "task frame has no moving joints"; return false; }
+  compose(ppos, pquat, lpos, lquat);
+  memcpy(D.post_pos, ppos, sizeof(ppos));
+  memcpy(D.post_quat, pquat, sizeof(pquat));
+  int nk = -1;
+  for (int s : kFusedSizes)
+    if (s >= nc) { nk = s; break; }
+  if (nk < 0) { why = "task chain longer than the fused kernels support"; return false; }
+  for (int k = nc; k < nk; ++k) {  // padding slots: no joint, unit Hessian entry
+    D.seg[k].type = 0;
+    D.seg[k].dof = -1;
+    D.seg[k].pre_quat[0] = 1.0;
+  }
+  D.nc = nc;
+  *nc_kernel = nk;
+  if (ft.ncost != 6) { why = "frame task cost must have 6 entries"; return false; }
+  memcpy(D.cost, ft.cost, 6 * sizeof(double));
+  D.gain = ft.gain;
+  D.lm = ft.lm_damping;
+  // posture-like tasks
+  for (int t = 0; t < ntask; ++t) {
+    if (tasks[t].type != MK_TASK_POSTURE) continue;
+    if (tasks[t].ncost != m.nv || !tasks[t].target_q) { why = "posture task needs nv costs and a target"; return false; }
+    MkPosture& P = D.posture[D.nposture++];
+    P.gain = tasks[t].gain;
+    P.lm = tasks[t].lm_damping;
+    for (int i = 0; i < m.nv; ++i) {
+      const bool scalar = D.dof[i].kind == MK_DOF_SCALAR;
+      P.cost[i] = scalar ? tasks[t].cost[i] : 0.0;
+      P.target[i] = scalar ? tasks[t].target_q[D.dof[i].qadr] : 0.0;
+    }
+  }
+  // box limits
+  auto add_term = [&](int dof, const MkBoundTerm& bt) -> bool {
+    MkDof& dd = D.dof[dof];
+    if (dd.nterm >= MK_MAX_TERMS) return false;
+    dd.term[dd.nterm++] = bt;
+    return true;
+  };
+  for (int l = 0; l < nlimit; ++l) {
+    const mk_limit_desc& L = limits[l];
+    if (L.type == MK_LIMIT_CONFIGURATION) {
+      for (int j = 0; j < m.njnt; ++j) {
+        if (m.jnt_type[j] == MK_JNT_FREE || !m.jnt_limited[j]) continue;
+        MkBoundTerm bt{MK_TERM_CFG, 0, m.jnt_range[2 * j] + L.min_distance_from_limits,
+                       m.jnt_range[2 * j + 1] - L.min_distance_from_limits, L.gain};
+        if (!add_term(m.jnt_dofadr[j], bt)) { why = "too many limits on one dof"; return false; }
+      }
+    } else if (L.type == MK_LIMIT_VELOCITY) {
+      for (int k = 0; k < L.n; ++k) {
+        const int dof = L.index[k];
+        if (dof < 0 || dof >= m.nv || D.dof[dof].kind != MK_DOF_SCALAR) { why = "velocity limit on an unsupported dof"; return false; }
+        MkBoundTerm bt{MK_TERM_VEL, 0, L.vmax[k], 0.0, 0.0};
+        if (!add_term(dof, bt)) { why = "too many limits on one dof"; return false; }
+      }
+    }
+  }
+  return true;
+}
+
+int count_rows(const HostModel& m, const mk_limit_desc* limits, int nlimit) {
+  int rows = 0;
+  for (int l = 0; l < nlimit; ++l) {
+    const mk_limit_desc& L = limits[l];
+    if (L.type == MK_LIMIT_CONFIGURATION) {
+      for (int j = 0; j < m.njnt; ++j)
+        if (m.jnt_type[j] != MK_JNT_FREE && m.jnt_limited[j]) rows += 2 * (m.jnt_type[j] == MK_JNT_BALL ? 3 : 1);
+    } else if (L.type == MK_LIMIT_VELOCITY) {
+      rows += 2 * L.n;
+    } else if (L.type == MK_LIMIT_COLLISION) {
+      rows += L.n;
+    }
+  }
+  return rows;
+}
+
+int host_model_from_desc(const mk_model_desc* d, HostModel& h) {
+  h.nq = d->nq; h.nv = d->nv; h.nbody = d->nbody; h.njnt = d->njnt; h.ngeom = d->ngeom; h.nsite = d->nsite;
+  h.body_parentid = copy_in(d->body_parentid, h.nbody);
+  h.body_jntadr = copy_in(d->body_jntadr, h.nbody);
+  h.body_jntnum = copy_in(d->body_jntnum, h.nbody);
+  h.body_mocapid = d->body_mocapid ? copy_in(d->body_mocapid, h.nbody) : std::vector<int32_t>(h.nbody, -1);
+  h.body_pos = copy_in(d->body_pos, 3 * h.nbody);
+  h.body_quat = copy_in(d->body_quat, 4 * h.nbody);
+  h.body_mass = copy_in(d->body_mass, h.nbody);
+  h.body_ipos = copy_in(d->body_ipos, 3 * h.nbody);
+  h.jnt_type = copy_in(d->jnt_type, h.njnt);
+  h.jnt_qposadr = copy_in(d->jnt_qposadr, h.njnt);
+  h.jnt_dofadr = copy_in(d->jnt_dofadr, h.njnt);
+  h.jnt_bodyid = copy_in(d->jnt_bodyid, h.njnt);
+  h.jnt_limited = copy_in(d->jnt_limited, h.njnt);
+  h.jnt_pos = copy_in(d->jnt_pos, 3 * h.njnt);
+  h.jnt_axis = copy_in(d->jnt_axis, 3 * h.njnt);
+  h.jnt_range = copy_in(d->jnt_range, 2 * h.njnt);
+  h.qpos0 = copy_in(d->qpos0, h.nq);
+  h.dof_parentid = copy_in(d->dof_parentid, h.nv);
+  h.dof_jntid = copy_in(d->dof_jntid, h.nv);
+  h.site_bodyid = copy_in(d->site_bodyid, h.nsite);
+  h.site_pos = copy_in(d->site_pos, 3 * h.nsite);
+  h.site_quat = copy_in(d->site_quat, 4 * h.nsite);
+  h.geom_bodyid = copy_in(d->geom_bodyid, h.ngeom);
+  h.geom_type = copy_in(d->geom_type, h.ngeom);
+  h.geom_size = copy_in(d->geom_size, 3 * h.ngeom);
+  h.geom_pos = copy_in(d->geom_pos, 3 * h.ngeom);
+  h.geom_quat = copy_in(d->geom_quat, 4 * h.ngeom);
+  // consistency checks the kernels rely on
+  int nq = 0, nv = 0;
+  for (int j = 0; j < h.njnt; ++j) {
+    const int t = h.jnt_type[j];
+    if (t < 0 || t > 3 || h.jnt_qposadr[j] != nq || h.jnt_dofadr[j] != nv || h.jnt_bodyid[j] <= 0 ||
+        h.jnt_bodyid[j] >= h.nbody) {
+      return fail(MK_ERR_INVALID, "joint %d: inconsistent type/address/body", j);
+    }
+    nq += (t == MK_JNT_FREE ? 7 : t == MK_JNT_BALL ? 4 : 1);
+    nv += (t == MK_JNT_FREE ? 6 : t == MK_JNT_BALL ? 3 : 1);
+  }
+  if (nq != h.nq || nv != h.nv) { return fail(MK_ERR_INVALID, "nq/nv do not match the joint table"); }
+  for (int b = 1; b < h.nbody; ++b) {
+    if (h.body_parentid[b] < 0 || h.body_parentid[b] >= b) { return fail(MK_ERR_INVALID, "body %d: parent must precede it", b); }
+    const int ja = h.body_jntadr[b], jn = h.body_jntnum[b];
+    if (jn < 0 || (jn > 0 && (ja < 0 || ja + jn > h.njnt))) { return fail(MK_ERR_INVALID, "body %d: joint range", b); }
+    for (int j = ja; j < ja + jn; ++j)
+      if (h.jnt_bodyid[j] != b || (h.jnt_type[j] == MK_JNT_FREE && jn != 1)) { return fail(MK_ERR_INVALID, "body %d: joint table", b); }
+  }
+  return MK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mk_last_error(void) { return g_last_error.c_str(); }
+
+int mk_model_create(const mk_model_desc* d, mk_model** out) {
+  if (!d || !out) return fail(MK_ERR_INVALID, "null argument");
+  if (d->nq <= 0 || d->nv <= 0 || d->nbody <= 0 || d->njnt <= 0) return fail(MK_ERR_INVALID, "empty model");
+  mk_model* m = new mk_model();
+  HostModel& h = m->h;
+  {
+    int rc0 = host_model_from_desc(d, h);
+    if (rc0 != MK_OK) { delete m; return rc0; }
+  }
+  if (hipGetDevice(&m->device) != hipSuccess) { delete m; return fail(MK_ERR_HIP, "hipGetDevice failed"); }
+  // paths root -> body, for the generic per-frame kernels
+  std::vector<int32_t> path_adr(h.nbody), path_len(h.nbody), path_data;
+  for (int b = 0; b < h.nbody; ++b) {
+    std::vector<int> p;
+    for (int x = b; x != 0; x = h.body_parentid[x]) p.insert(p.begin(), x);
+    path_adr[b] = (int32_t)path_data.size();
+    path_len[b] = (int32_t)p.size();
+    path_data.insert(path_data.end(), p.begin(), p.end());
+  }
+  MkDevModel& dv = m->dev;
+  memset(&dv, 0, sizeof(dv));
+  dv.nq = h.nq; dv.nv = h.nv; dv.nbody = h.nbody; dv.njnt = h.njnt;
+  int rc = MK_OK;
+#define UP(field) if (rc == MK_OK) rc = upload(m->allocs, h.field, &dv.field)
+  UP(body_parentid); UP(body_jntadr); UP(body_jntnum); UP(body_mocapid); UP(body_pos); UP(body_quat);
+  UP(jnt_type); UP(jnt_qposadr); UP(jnt_dofadr); UP(jnt_bodyid); UP(jnt_limited); UP(jnt_pos); UP(jnt_axis);
+  UP(jnt_range); UP(qpos0);
+#undef UP
+  if (rc == MK_OK) rc = upload(m->allocs, path_adr, &dv.path_adr);
+  if (rc == MK_OK) rc = upload(m->allocs, path_len, &dv.path_len);
+  if (rc == MK_OK) rc = upload(m->allocs, path_data, &dv.path_data);
+  if (rc != MK_OK) { mk_model_destroy(m); return rc; }
+  *out = m;
+  return MK_OK;
+}
+
+void mk_model_destroy(mk_model* m) {
+  if (!m) return;
+  for (void* p : m->allocs) (void)hipFree(p);
+  delete m;
+}
+
+int mk_problem_create(const mk_model* model, const mk_task_desc* tasks, int32_t ntask, const mk_limit_desc* limits,
+                      int32_t nlimit, mk_problem** out) {
+  if (!model || !out || ntask < 0 || nlimit < 0 || (ntask > 0 && !tasks) || (nlimit > 0 && !limits))
+    return fail(MK_ERR_INVALID, "null or negative argument");
+  const HostModel& m = model->h;
+  int stride = 0;
+  for (int t = 0; t < ntask; ++t) {
+    const mk_task_desc& T = tasks[t];
+    if (!(T.gain >= 0.0 && T.gain <= 1.0)) return fail(MK_ERR_INVALID, "task %d: gain must be in [0, 1]", t);
+    if (!(T.lm_damping >= 0.0)) return fail(MK_ERR_INVALID, "task %d: lm_damping must be >= 0", t);
+    if (!T.cost) return fail(MK_ERR_INVALID, "task %d: cost is null", t);
+    for (int i = 0; i < T.ncost; ++i)
+      if (!(T.cost[i] >= 0.0)) return fail(MK_ERR_INVALID, "task %d: cost must be >= 0", t);
+    if (T.type == MK_TASK_FRAME || T.type == MK_TASK_RELATIVE_FRAME) stride += 7;
+    else if (T.type == MK_TASK_COM) stride += 3;
+    else if (T.type != MK_TASK_POSTURE) return fail(MK_ERR_INVALID, "task %d: unknown type %d", t, T.type);
+  }
+  for (int l = 0; l < nlimit; ++l) {
+    const mk_limit_desc& L = limits[l];
+    if (L.type == MK_LIMIT_CONFIGURATION) {
+      if (!(L.gain > 0.0 && L.gain <= 1.0)) return fail(MK_ERR_INVALID, "limit %d: gain must be in (0, 1]", l);
+    } else if (L.type == MK_LIMIT_VELOCITY) {
+      if (L.n < 0 || (L.n > 0 && (!L.index || !L.vmax))) return fail(MK_ERR_INVALID, "limit %d: velocity arrays", l);
+    } else if (L.type == MK_LIMIT_COLLISION) {
+      if (L.n < 0 || (L.n > 0 && !L.index)) return fail(MK_ERR_INVALID, "limit %d: geom pairs", l);
+    } else {
+      return fail(MK_ERR_INVALID, "limit %d: unknown type %d", l, L.type);
+    }
+  }
+  mk_problem* p = new mk_problem();
+  p->model = model;
+  p->d_fused = nullptr;
+  memset(&p->gen, 0, sizeof(p->gen));
+  p->info.nq = m.nq;
+  p->info.nv = m.nv;
+  p->info.target_stride = stride;
+  p->info.n_rows = count_rows(m, limits, nlimit);
+  std::string why;
+  p->fused = build_fused(m, tasks, ntask, limits, nlimit, p->h_fused, &p->nc_kernel, why);
+  p->info.fused = p->fused ? 1 : 0;
+  p->info.n_chain = p->fused ? p->h_fused.nc : 0;
+  if (p->fused) {
+    void* d = nullptr;
+    if (hipMalloc(&d, sizeof(MkFusedDesc)) != hipSuccess ||
+        hipMemcpy(d, &p->h_fused, sizeof(MkFusedDesc), hipMemcpyHostToDevice) != hipSuccess) {
+      if (d) (void)hipFree(d);
+      delete p;
+      return fail(MK_ERR_HIP, "could not upload the problem descriptor");
+    }
+    p->d_fused = static_cast<MkFusedDesc*>(d);
+    p->allocs.push_back(d);
+  } else {
+    g_last_error = "dense path required: " + why;
+  }
+  *out = p;
+  return MK_OK;
+}
+
+void mk_problem_destroy(mk_problem* p) {
+  if (!p) return;
+  for (void* a : p->allocs) (void)hipFree(a);
+  delete p;
+}
+
+int mk_problem_get_info(const mk_problem* p, mk_problem_info* info) {
+  if (!p || !info) return fail(MK_ERR_INVALID, "null argument");
+  *info = p->info;
+  return MK_OK;
+}
+
+int mk_solve_ik_batch(const mk_problem* p, const double* d_q, const double* d_targets, double dt, double damping,
+                      int32_t B, double* d_v, int32_t* d_status, void* stream) {
+  if (!p) return fail(MK_ERR_INVALID, "null problem");
+  if (B < 0 || !(dt > 0.0) || !(damping >= 0.0)) return fail(MK_ERR_INVALID, "B, dt or damping out of range");
+  if (B == 0) return MK_OK;
+  if (!d_q || !d_v || !d_status) return fail(MK_ERR_INVALID, "null argument");
+  if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
+  if (!p->fused) return fail(MK_ERR_UNSUPPORTED, "this task/limit set needs the dense path (mk_build_qp_batch + mk_qp_solve_batch)");
+  MK_HIP(mk_fused_launch_step(p->nc_kernel, p->d_fused, p->info.nq, d_q, d_targets, p->info.target_stride, dt,
+                              damping, B, d_v, d_status, static_cast<hipStream_t>(stream)));
+  return MK_OK;
+}
+
+int mk_solve_ik_iterate_batch(const mk_problem* p, double* d_q, const double* d_targets, double dt, double damping,
+                              int32_t B, int32_t max_iters, double pos_tol, double ori_tol, double* d_v,
+                              int32_t* d_iters, double* d_err, int32_t* d_status, void* stream) {
+  if (!p) return fail(MK_ERR_INVALID, "null problem");
+  if (B < 0 || max_iters < 0 || !(dt > 0.0) || !(damping >= 0.0)) return fail(MK_ERR_INVALID, "B, max_iters, dt or damping out of range");
+  if (B == 0) return MK_OK;
+  if (!d_q || !d_status) return fail(MK_ERR_INVALID, "null argument");
+  if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
+  if (!p->fused) return fail(MK_ERR_UNSUPPORTED, "the iterated solve needs a problem the fused path serves");
+  MK_HIP(mk_fused_launch_iterate(p->nc_kernel, p->d_fused, p->info.nq, d_q, d_targets, p->info.target_stride, dt,
+                                 damping, B, max_iters, pos_tol, ori_tol, d_v, d_iters, d_err, d_status,
+                                 static_cast<hipStream_t>(stream)));
+  return MK_OK;
+}
+
+int mk_integrate_batch(const mk_model* m, double* d_q, const double* d_v, double dt, int32_t B, void* stream) {
+  if (!m || B < 0) return fail(MK_ERR_INVALID, "null model or negative batch");
+  if (B == 0) return MK_OK;
+  if (!d_q || !d_v) return fail(MK_ERR_INVALID, "null argument");
+  MK_HIP(mk_generic_integrate(m->dev, d_q, d_v, dt, B, static_cast<hipStream_t>(stream)));
+  return MK_OK;
+}
+
+int mk_fk_batch(const mk_model* m, const double* d_q, int32_t B, int32_t frame_type, int32_t frame_id, double* d_pose,
+                void* stream) {
+  if (!m || B < 0) return fail(MK_ERR_INVALID, "null model or negative batch");
+  if (B > 0 && (!d_q || !d_pose)) return fail(MK_ERR_INVALID, "null argument");
+  int body;
+  double lpos[3], lquat[4];
+  int rc = frame_body_and_local(m->h, frame_type, frame_id, &body, lpos, lquat);
+  if (rc != MK_OK) return rc;
+  if (B == 0) return MK_OK;
+  MK_HIP(mk_generic_frame(m->dev, d_q, B, body, lpos, lquat, d_pose, nullptr, static_cast<hipStream_t>(stream)));
+  return MK_OK;
+}
+
+int mk_frame_jacobian_batch(const mk_model* m, const double* d_q, int32_t B, int32_t frame_type, int32_t frame_id,
+                            double* d_jac, void* stream) {
+  if (!m || B < 0) return fail(MK_ERR_INVALID, "null model or negative batch");
+  if (B > 0 && (!d_q || !d_jac)) return fail(MK_ERR_INVALID, "null argument");
+  int body;
+  double lpos[3], lquat[4];
+  int rc = frame_body_and_local(m->h, frame_type, frame_id, &body, lpos, lquat);
+  if (rc != MK_OK) return rc;
+  if (B == 0) return MK_OK;
+  MK_HIP(mk_generic_frame(m->dev, d_q, B, body, lpos, lquat, nullptr, d_jac, static_cast<hipStream_t>(stream)));
+  return MK_OK;
+}
+
+int mk_check_limits_batch(const mk_model* m, const double* d_q, double tol, int32_t B, int32_t* d_first, void* stream) {
+  if (!m || B < 0) return fail(MK_ERR_INVALID, "null model or negative batch");
+  if (B == 0) return MK_OK;
+  if (!d_q || !d_first) return fail(MK_ERR_INVALID, "null argument");
+  MK_HIP(mk_generic_check_limits(m->dev, d_q, tol, B, d_first, static_cast<hipStream_t>(stream)));
+  return MK_OK;
+}
+
+int mk_build_qp_batch(const mk_problem* p, const double* d_q, const double* d_targets, double dt, double damping,
+                      int32_t B, double* d_P, double* d_c, double* d_G, double* d_h, void* stream) {
+  (void)p; (void)d_q; (void)d_targets; (void)dt; (void)damping; (void)B; (void)d_P; (void)d_c; (void)d_G; (void)d_h; (void)stream;
+  return fail(MK_ERR_UNSUPPORTED, "mk_build_qp_batch is not implemented yet");
+}
+
+int mk_qp_solve_batch(const double* d_P, const double* d_c, const double* d_G, const double* d_h, int32_t n, int32_t m,
+                      int32_t B, double* d_x, int32_t* d_status, void* stream) {
+  (void)d_P; (void)d_c; (void)d_G; (void)d_h; (void)n; (void)m; (void)B; (void)d_x; (void)d_status; (void)stream;
+  return fail(MK_ERR_UNSUPPORTED, "mk_qp_solve_batch is not implemented yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,245 @@
+// Device-side building blocks shared by the mink_amd kernels: small fixed-size
+// vector / quaternion / SE3 helpers and the problem descriptors that the host
+// flattens out of mk_model_desc / mk_task_desc / mk_limit_desc.
+//
+// Everything is float64, one IK problem per lane; descriptors are wave-uniform, so
+// descriptor reads become scalar loads.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Math helpers are host+device so that the same source can be exercised lane by lane
+// in a host-compiled unit-test build (tests/hostsim); the library itself only ever
+// runs them inside kernels.
+#define MK_DEV __host__ __device__ __forceinline__
+
+constexpr int MK_MAX_CHAIN = 12;   // dofs with dense coupling in the fused path
+constexpr int MK_MAX_NV = 64;      // tangent dimension supported by the fused path
+constexpr int MK_MAX_NQ = 72;
+constexpr int MK_MAX_POSTURE = 4;  // posture-like tasks per problem (fused path)
+constexpr int MK_MAX_TERMS = 4;    // box-limit terms per dof
+constexpr double MK_LIE_EPS = 1e-10;  // mink/lie/utils.py:4-8, float64
+constexpr double MK_MINVAL = 1e-15;   // MuJoCo mjMINVAL
+constexpr double MK_PI = 3.14159265358979323846;
+
+enum { MK_SEG_SLIDE = 2, MK_SEG_HINGE = 3 };
+enum { MK_SEG_HAS_PRE = 1, MK_SEG_END_BODY = 2, MK_SEG_HAS_JPOS = 4, MK_SEG_AXIS_Z = 8 };
+enum { MK_TERM_CFG = 0, MK_TERM_VEL = 1 };
+enum { MK_DOF_SCALAR = 0, MK_DOF_FREE_LIN = 1, MK_DOF_FREE_ROT = 2, MK_DOF_BALL = 3 };
+
+// One 1-dof joint of the kinematic chain from the world to the task frame,
+// preceded by the fixed transform that leads to the joint's body.
+struct MkSeg {
+  double pre_pos[3];
+  double pre_quat[4];
+  double jpos[3];   // joint anchor in the body frame
+  double axis[3];   // joint axis in the body frame
+  double qpos0;
+  int32_t type;     // MK_SEG_SLIDE / MK_SEG_HINGE
+  int32_t flags;
+  int32_t qadr;
+  int32_t dof;
+};
+
+struct MkBoundTerm {
+  int32_t kind;   // MK_TERM_CFG: a = lower, b = upper, gain; MK_TERM_VEL: a = vmax
+  int32_t pad;
+  double a, b, gain;
+};
+
+struct MkDof {
+  int32_t qadr;
+  int32_t kind;   // MK_DOF_*
+  int32_t slot;   // index in the dense block, or -1
+  int32_t nterm;
+  MkBoundTerm term[MK_MAX_TERMS];
+};
+
+struct MkPosture {
+  double gain, lm;
+  double cost[MK_MAX_NV];     // per dof (free-joint dofs forced to 0)
+  double target[MK_MAX_NV];   // target qpos of the dof's (scalar) joint
+};
+
+struct MkFusedDesc {
+  int32_t nq, nv, nc, nposture;
+  int32_t nfree, target_off, pad0, pad1;
+  int32_t free_qadr[8];        // qpos address of each free joint (7 values)
+  MkSeg seg[MK_MAX_CHAIN];
+  double post_pos[3], post_quat[4];   // last chain body -> task frame
+  double cost[6], gain, lm;           // frame task
+  MkPosture posture[MK_MAX_POSTURE];
+  MkDof dof[MK_MAX_NV];
+};
+
+// ------------------------------------------------------------------ math ----
+MK_DEV double mk_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return rsqrt(x);
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+// True when no lane of the wave still has `pending` set.
+MK_DEV bool mk_wave_none(bool pending) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __ballot(pending) == 0ull;
+#else
+  return !pending;
+#endif
+}
+
+struct V3 { double x, y, z; };
+struct Q4 { double w, x, y, z; };
+struct M3 { double m[9]; };  // row-major
+
+MK_DEV V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+MK_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+MK_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+MK_DEV V3 operator*(double s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+MK_DEV V3 neg(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+MK_DEV double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+MK_DEV V3 cross(V3 a, V3 b) {
+  return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// Hamilton product (mju_mulQuat).
+MK_DEV Q4 qmul(Q4 a, Q4 b) {
+  return Q4{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
+            a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+            a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+MK_DEV Q4 qconj(Q4 a) { return Q4{a.w, -a.x, -a.y, -a.z}; }
+
+// mju_normalize4: a vanishing quaternion maps to identity.
+MK_DEV Q4 qnormalize(Q4 q) {
+  double n = sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  if (n < MK_MINVAL) return Q4{1.0, 0.0, 0.0, 0.0};
+  return Q4{q.w / n, q.x / n, q.y / n, q.z / n};
+}
+
+// mju_quat2Mat.
+MK_DEV M3 q2m(Q4 q) {
+  double q00 = q.w * q.w, q11 = q.x * q.x, q22 = q.y * q.y, q33 = q.z * q.z;
+  double q01 = q.w * q.x, q02 = q.w * q.y, q03 = q.w * q.z;
+  double q12 = q.x * q.y, q13 = q.x * q.z, q23 = q.y * q.z;
+  M3 r;
+  r.m[0] = q00 + q11 - q22 - q33; r.m[1] = 2 * (q12 - q03); r.m[2] = 2 * (q13 + q02);
+  r.m[3] = 2 * (q12 + q03); r.m[4] = q00 - q11 + q22 - q33; r.m[5] = 2 * (q23 - q01);
+  r.m[6] = 2 * (q13 - q02); r.m[7] = 2 * (q23 + q01); r.m[8] = q00 - q11 - q22 + q33;
+  return r;
+}
+MK_DEV V3 mul(const M3& r, V3 v) {
+  return V3{r.m[0] * v.x + r.m[1] * v.y + r.m[2] * v.z,
+            r.m[3] * v.x + r.m[4] * v.y + r.m[5] * v.z,
+            r.m[6] * v.x + r.m[7] * v.y + r.m[8] * v.z};
+}
+MK_DEV V3 mulT(const M3& r, V3 v) {
+  return V3{r.m[0] * v.x + r.m[3] * v.y + r.m[6] * v.z,
+            r.m[1] * v.x + r.m[4] * v.y + r.m[7] * v.z,
+            r.m[2] * v.x + r.m[5] * v.y + r.m[8] * v.z};
+}
+MK_DEV M3 mmul(const M3& a, const M3& b) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      r.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+  return r;
+}
+// I + a*[w]x + b*[w]x^2
+MK_DEV M3 rodrigues_like(V3 w, double a, double b) {
+  double xx = w.x * w.x, yy = w.y * w.y, zz = w.z * w.z;
+  double xy = w.x * w.y, xz = w.x * w.z, yz = w.y * w.z;
+  M3 r;
+  r.m[0] = 1.0 - b * (yy + zz); r.m[1] = -a * w.z + b * xy; r.m[2] = a * w.y + b * xz;
+  r.m[3] = a * w.z + b * xy; r.m[4] = 1.0 - b * (xx + zz); r.m[5] = -a * w.x + b * yz;
+  r.m[6] = -a * w.y + b * xz; r.m[7] = a * w.x + b * yz; r.m[8] = 1.0 - b * (xx + yy);
+  return r;
+}
+MK_DEV M3 skew(V3 w) {
+  M3 r;
+  r.m[0] = 0; r.m[1] = -w.z; r.m[2] = w.y;
+  r.m[3] = w.z; r.m[4] = 0; r.m[5] = -w.x;
+  r.m[6] = -w.y; r.m[7] = w.x; r.m[8] = 0;
+  return r;
+}
+MK_DEV M3 mtrans(const M3& a) {
+  M3 r;
+  r.m[0] = a.m[0]; r.m[1] = a.m[3]; r.m[2] = a.m[6];
+  r.m[3] = a.m[1]; r.m[4] = a.m[4]; r.m[5] = a.m[7];
+  r.m[6] = a.m[2]; r.m[7] = a.m[5]; r.m[8] = a.m[8];
+  return r;
+}
+
+// SO3.log of a unit quaternion (mink/lie/so3.py:176-191), safe for w < 0.
+MK_DEV V3 so3_log(Q4 q) {
+  double n2 = q.x * q.x + q.y * q.y + q.z * q.z;
+  double f;
+  if (n2 < MK_LIE_EPS) {
+    f = 2.0 / q.w - 2.0 / 3.0 * n2 / (q.w * q.w * q.w);
+  } else {
+    double n = sqrt(n2);
+    if (fabs(q.w) < MK_LIE_EPS) {
+      f = (q.w > 0.0 ? 1.0 : -1.0) * MK_PI / n;
+    } else {
+      f = 2.0 * atan2(q.w < 0 ? -n : n, fabs(q.w)) / n;
+    }
+  }
+  return V3{f * q.x, f * q.y, f * q.z};
+}
+
+struct Twist { V3 v, w; };
+
+// SE3.log (mink/lie/se3.py:159-185) of the transform (q, t).
+MK_DEV Twist se3_log(Q4 q, V3 t) {
+  V3 w = so3_log(q);
+  double t2 = dot(w, w);
+  double coef;
+  if (t2 < MK_LIE_EPS) {
+    coef = 1.0 / 12.0;
+  } else {
+    double th = sqrt(t2), h = 0.5 * th;
+    double s, c;
+    sincos(h, &s, &c);
+    coef = (1.0 - th * c / (2.0 * s)) / t2;
+  }
+  M3 Vinv = rodrigues_like(w, -0.5, coef);
+  return Twist{mul(Vinv, t), w};
+}
+
+// Blocks of SE3.ljacinv(xi) = [[Ji, B], [0, Ji]] with B = -Ji Q Ji
+// (mink/lie/se3.py:210-249, mink/lie/so3.py:214-226). Returns false when the
+// reference returns exactly I6 (theta^2 below the switch).
+MK_DEV bool se3_ljacinv_blocks(Twist xi, M3& Ji, M3& B) {
+  double t2 = dot(xi.w, xi.w);
+  if (t2 < MK_LIE_EPS) return false;
+  double th = sqrt(t2);
+  double s, c;
+  sincos(th, &s, &c);
+  // SO3.ljacinv switches on theta (not theta^2); theta >= 1e-5 here, so closed form.
+  double A = (1.0 / t2) * (1.0 - (th * s / (2.0 * (1.0 - c))));
+  Ji = rodrigues_like(xi.w, -0.5, A);
+  double Bc = (th - s) / (t2 * th);
+  double Cc = (1.0 - t2 / 2.0 - c) / (t2 * t2);
+  double Dc = (2.0 * th - 3.0 * s + th * c) / (2.0 * t2 * t2 * th);
+  M3 V = skew(xi.v), W = skew(xi.w);
+  M3 VW = mmul(V, W), WV = mtrans(VW);
+  M3 WVW = mmul(WV, W), VWW = mmul(VW, W);
+  M3 WVWW = mmul(WVW, W), WWVW = mmul(W, WVW);
+  M3 Q;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    int tr = (i % 3) * 3 + i / 3;
+    Q.m[i] = 0.5 * V.m[i] + Bc * (WV.m[i] + VW.m[i] + WVW.m[i]) -
+             Cc * (VWW.m[i] - VWW.m[tr] - 3.0 * WVW.m[i]) + Dc * (WVWW.m[i] + WWVW.m[i]);
+  }
+  M3 JQ = mmul(Ji, Q);
+  B = mmul(JQ, Ji);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) B.m[i] = -B.m[i];
+  return true;
+}

@@ -1,0 +1,554 @@
+// Fused differential-IK kernels: one IK problem per lane, 64 problems per wave.
+//
+// Per problem and per step the kernel does, entirely in registers + one LDS tile:
+//   forward kinematics along the chain to the task frame      (mj_kinematics, K1)
+//   body-frame frame Jacobian on the chain dofs                (mj_jacSite + configuration.py:143-153)
+//   e = log(T_wb^-1 T_wt), J = -jlog(T_wt^-1 T_wb) J_b          (frame_task.py:95-146)
+//   H = damping I + sum_t (Jw'Jw + mu I), c = -sum_t ew'Jw       (task.py:125-138, solve_ik.py:13-22)
+//   box limits from ConfigurationLimit / VelocityLimit          (configuration_limit.py:98-124,
+//                                                                 velocity_limit.py:96-101)
+//   exact QP solve, v = dq / dt                                 (solve_ik.py:101-105)
+//   optionally q <- q (+) dt v and the loop of teleop_mouse.py:105-121.
+//
+// Structure used: with a single frame task whose chain has NC 1-dof joints, H is a
+// dense NC x NC block on the chain dofs plus a diagonal on all other dofs, and the
+// limits are per-dof boxes; dofs outside the chain therefore decouple into clamps and
+// the dense block is solved by a dual active-set method (Goldfarb-Idnani iterates)
+// with the active bounds expressed as lane masks, so 64 problems with different
+// active sets run one instruction stream.
+#include "mk_device.h"
+
+namespace {
+
+MK_DEV constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+// Cholesky factor of H with the rows/columns in `act` replaced by identity.
+// L holds the strict lower triangle, Ld the reciprocals of the diagonal.
+template <int N>
+MK_DEV void chol_masked(const double (&H)[N * (N + 1) / 2], uint32_t act, double (&L)[N * (N + 1) / 2],
+                        double (&Ld)[N]) {
+  double mk[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) mk[i] = ((act >> i) & 1u) ? 0.0 : 1.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double s = mk[j] * H[tri(j, j)] + (1.0 - mk[j]);
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[tri(j, k)] * L[tri(j, k)];
+    s = fmax(s, 1e-300);
+    double r = mk_rsqrt(s);
+    Ld[j] = r;
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) {
+      double t = (mk[i] * mk[j]) * H[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[tri(i, k)] * L[tri(j, k)];
+      L[tri(i, j)] = t * r;
+    }
+  }
+}
+
+// In-place solve of (L L') y = b.
+template <int N>
+MK_DEV void chol_solve(const double (&L)[N * (N + 1) / 2], const double (&Ld)[N], double (&b)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= L[tri(i, k)] * b[k];
+    b[i] = s * Ld[i];
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    double s = b[i];
+#pragma unroll
+    for (int k = i + 1; k < N; ++k) s -= L[tri(k, i)] * b[k];
+    b[i] = s * Ld[i];
+  }
+}
+
+// min 1/2 x'Hx + c'x  s.t. lo <= x <= hi, H positive definite (dense N x N).
+// Dual active-set method: start from the unconstrained minimiser; pick the most
+// violated bound p; move along the direction that keeps the active bounds tight
+// until p is satisfied (full step) or a multiplier reaches zero (partial step: that
+// bound leaves the active set).  Returns 0 ok / 1 iteration limit / 2 infeasible.
+template <int N>
+MK_DEV int box_qp(const double (&H)[N * (N + 1) / 2], const double (&c)[N], const double (&lo)[N],
+                  const double (&hi)[N], double (&x)[N]) {
+  double L[N * (N + 1) / 2], Ld[N];
+  double u[N];
+  uint32_t act = 0u, upper = 0u;
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    u[i] = 0.0;
+    bad |= !(lo[i] <= hi[i]);
+  }
+  chol_masked<N>(H, 0u, L, Ld);
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = -c[i];
+  chol_solve<N>(L, Ld, x);
+
+  int status = bad ? 2 : 0;
+  bool done = bad;
+  int p = -1;
+  double sgn = 0.0, bound = 0.0, up_new = 0.0;
+  for (int it = 0; it < 6 * N + 8; ++it) {
+    if (!done) {
+      if (p < 0) {
+        double worst = 1e-14;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          bool free_i = !((act >> i) & 1u);
+          double vh = x[i] - hi[i], vl = lo[i] - x[i];
+          if (free_i && vh > worst) { worst = vh; p = i; sgn = 1.0; bound = hi[i]; }
+          if (free_i && vl > worst) { worst = vl; p = i; sgn = -1.0; bound = lo[i]; }
+        }
+        up_new = 0.0;
+        if (p < 0) done = true;
+      }
+    }
+    if (mk_wave_none(!done)) break;
+    if (!done) {
+      chol_masked<N>(H, act, L, Ld);
+      double z[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) z[i] = (i == p) ? -sgn : 0.0;
+      chol_solve<N>(L, Ld, z);
+      // dual step direction of the active bounds and the blocking one
+      double t1 = INFINITY;
+      int kb = -1;
+      double xp = 0.0, zp = 0.0;
+      double r[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        double hz = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) hz += H[tri(k, j)] * z[j];
+        const bool a = (act >> k) & 1u;
+        r[k] = ((upper >> k) & 1u) ? hz : -hz;
+        if (a && r[k] > 0.0) {
+          double t = u[k] / r[k];
+          if (t < t1) { t1 = t; kb = k; }
+        }
+        if (k == p) { xp = x[k]; zp = z[k]; }
+      }
+      const double t2 = (bound - xp) / zp;
+      const bool full = t2 <= t1;
+      const double t = full ? t2 : t1;
+      up_new += t;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const bool a = (act >> k) & 1u;
+        x[k] += t * z[k];
+        if (a) u[k] = fmax(u[k] - t * r[k], 0.0);
+        if (full && k == p) { x[k] = bound; u[k] = up_new; }
+        if (!full && k == kb) u[k] = 0.0;
+      }
+      if (full) {
+        act |= (1u << p);
+        if (sgn > 0.0) upper |= (1u << p); else upper &= ~(1u << p);
+        p = -1;
+      } else {
+        act &= ~(1u << kb);
+      }
+    }
+  }
+  if (!done) status = 1;
+  return status;
+}
+
+// Chain kinematics of one problem: joint anchors / axes in the world frame, the task
+// frame pose and the frame-task error e = log(T_wb^-1 T_wt).
+template <int NC>
+struct ChainFK {
+  V3 anchor[NC], axw[NC];
+  V3 ps;
+  M3 Rs;
+  Twist e;
+};
+
+template <int NC>
+MK_DEV void chain_fk(const MkFusedDesc* __restrict__ D, const double (&qc)[NC], Q4 Qt, V3 pt, ChainFK<NC>& fk) {
+  V3 p = v3(0, 0, 0);
+  Q4 Q = Q4{1, 0, 0, 0};
+  M3 R;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const MkSeg& s = D->seg[k];
+    const int fl = s.flags;
+    if (s.type == 0) {  // padding slot
+      fk.axw[k] = v3(0, 0, 0);
+      fk.anchor[k] = v3(0, 0, 0);
+      continue;
+    }
+    if (fl & MK_SEG_HAS_PRE) {
+      p = p + mul(R, v3(s.pre_pos[0], s.pre_pos[1], s.pre_pos[2]));
+      Q = qmul(Q, Q4{s.pre_quat[0], s.pre_quat[1], s.pre_quat[2], s.pre_quat[3]});
+      R = q2m(Q);
+    }
+    V3 ax = (fl & MK_SEG_AXIS_Z) ? v3(R.m[2], R.m[5], R.m[8]) : mul(R, v3(s.axis[0], s.axis[1], s.axis[2]));
+    V3 an = (fl & MK_SEG_HAS_JPOS) ? p + mul(R, v3(s.jpos[0], s.jpos[1], s.jpos[2])) : p;
+    fk.axw[k] = ax;
+    fk.anchor[k] = an;
+    double dq = qc[k] - s.qpos0;
+    if (s.type == MK_SEG_SLIDE) {
+      p = p + dq * ax;
+    } else {
+      double sn, cs;
+      sincos(0.5 * dq, &sn, &cs);
+      Q = qmul(Q, Q4{cs, sn * s.axis[0], sn * s.axis[1], sn * s.axis[2]});
+      if ((fl & MK_SEG_HAS_JPOS) || !(fl & MK_SEG_END_BODY)) {
+        R = q2m(Q);
+        if (fl & MK_SEG_HAS_JPOS) p = an - mul(R, v3(s.jpos[0], s.jpos[1], s.jpos[2]));
+      }
+    }
+    if (fl & MK_SEG_END_BODY) {
+      Q = qnormalize(Q);
+      R = q2m(Q);
+    }
+  }
+  fk.ps = p + mul(R, v3(D->post_pos[0], D->post_pos[1], D->post_pos[2]));
+  Q4 Qs = qmul(Q, Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]});
+  fk.Rs = q2m(Qs);
+  fk.e = se3_log(qmul(qconj(Qs), Qt), mulT(fk.Rs, pt - fk.ps));
+}
+
+// Builds and solves the QP of one problem from its chain kinematics. `row` is the
+// lane's q row in LDS. On return x holds dq of the chain dofs; the other dofs are
+// handled in place:
+//   INTEGRATE == false: row[dof] <- v[dof] for every non-chain dof (q is consumed)
+//   INTEGRATE == true : row[qadr] <- q (+) dt v for every non-chain dof, and their
+//                       velocity goes to vrow[dof] when vrow is not null
+template <int NC, bool INTEGRATE>
+MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const double (&qc)[NC],
+                         const ChainFK<NC>& fk, double dt, double damping, double (&x)[NC], double* vrow) {
+  const Twist e = fk.e;
+  const V3 ps = fk.ps;
+  const M3 Rs = fk.Rs;
+  M3 Ji, Bm;
+  const bool full_jlog = se3_ljacinv_blocks(e, Ji, Bm);
+  double cost[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) cost[r] = D->cost[r];
+  double Jw[6][NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const bool hinge = D->seg[k].type == MK_SEG_HINGE;
+    V3 jp = hinge ? cross(fk.axw[k], ps - fk.anchor[k]) : fk.axw[k];
+    V3 bl = mulT(Rs, jp);
+    V3 ba = hinge ? mulT(Rs, fk.axw[k]) : v3(0, 0, 0);
+    V3 tl, ta;
+    if (full_jlog) {
+      tl = neg(mul(Ji, bl) + mul(Bm, ba));
+      ta = neg(mul(Ji, ba));
+    } else {
+      tl = neg(bl);
+      ta = neg(ba);
+    }
+    Jw[0][k] = cost[0] * tl.x; Jw[1][k] = cost[1] * tl.y; Jw[2][k] = cost[2] * tl.z;
+    Jw[3][k] = cost[3] * ta.x; Jw[4][k] = cost[4] * ta.y; Jw[5][k] = cost[5] * ta.z;
+  }
+  const double g = D->gain;
+  double ew[6] = {cost[0] * (-g * e.v.x), cost[1] * (-g * e.v.y), cost[2] * (-g * e.v.z),
+                  cost[3] * (-g * e.w.x), cost[4] * (-g * e.w.y), cost[5] * (-g * e.w.z)};
+  double diag = damping + D->lm * (ew[0] * ew[0] + ew[1] * ew[1] + ew[2] * ew[2] + ew[3] * ew[3] +
+                                   ew[4] * ew[4] + ew[5] * ew[5]);
+  // Levenberg-Marquardt terms of posture tasks need the error over every dof.
+  for (int t = 0; t < D->nposture; ++t) {
+    const MkPosture& P = D->posture[t];
+    if (P.lm > 0.0) {
+      double s2 = 0.0;
+      for (int i = 0; i < D->nv; ++i) {
+        if (D->dof[i].kind != MK_DOF_SCALAR) continue;
+        double ewi = P.cost[i] * (-P.gain * (P.target[i] - row[D->dof[i].qadr]));
+        s2 += ewi * ewi;
+      }
+      diag += P.lm * s2;
+    }
+  }
+
+  double H[NC * (NC + 1) / 2], c[NC], lo[NC], hi[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) s += Jw[r][i] * Jw[r][j];
+      H[tri(i, j)] = s;
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) s += ew[r] * Jw[r][i];
+    c[i] = -s;
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int dofk = D->seg[k].dof;
+    if (dofk < 0) {  // padding slot: decoupled unit entry, solution 0
+      H[tri(k, k)] = 1.0;
+      c[k] = 0.0;
+      lo[k] = -INFINITY;
+      hi[k] = INFINITY;
+      continue;
+    }
+    double hkk = H[tri(k, k)] + diag;
+    double ck = c[k];
+    for (int t = 0; t < D->nposture; ++t) {
+      const MkPosture& P = D->posture[t];
+      double cst = P.cost[dofk];
+      double ewi = cst * (-P.gain * (P.target[dofk] - qc[k]));
+      hkk += cst * cst;
+      ck += ewi * cst;
+    }
+    H[tri(k, k)] = hkk;
+    c[k] = ck;
+    const MkDof& dd = D->dof[dofk];
+    double l = -INFINITY, h = INFINITY;
+    for (int t = 0; t < dd.nterm; ++t) {
+      const MkBoundTerm& bt = dd.term[t];
+      if (bt.kind == MK_TERM_CFG) {
+        h = fmin(h, bt.gain * (bt.b - qc[k]));
+        l = fmax(l, -(bt.gain * (qc[k] - bt.a)));
+      } else {
+        h = fmin(h, dt * bt.a);
+        l = fmax(l, -(dt * bt.a));
+      }
+    }
+    lo[k] = l;
+    hi[k] = h;
+  }
+
+  int status = box_qp<NC>(H, c, lo, hi, x);
+
+  // ---- dofs outside the chain: diagonal Hessian, box limits -> clamp ----
+  for (int i = 0; i < D->nv; ++i) {
+    const MkDof& dd = D->dof[i];
+    if (dd.slot >= 0) continue;
+    if (dd.kind != MK_DOF_SCALAR) {
+      if (!INTEGRATE) row[i] = 0.0; else if (vrow) vrow[i] = 0.0;
+      continue;
+    }
+    const double qi = row[dd.qadr];
+    double hii = diag, ci = 0.0;
+    for (int t = 0; t < D->nposture; ++t) {
+      const MkPosture& P = D->posture[t];
+      double cst = P.cost[i];
+      double ewi = cst * (-P.gain * (P.target[i] - qi));
+      hii += cst * cst;
+      ci += ewi * cst;
+    }
+    double l = -INFINITY, h = INFINITY;
+    for (int t = 0; t < dd.nterm; ++t) {
+      const MkBoundTerm& bt = dd.term[t];
+      if (bt.kind == MK_TERM_CFG) {
+        h = fmin(h, bt.gain * (bt.b - qi));
+        l = fmax(l, -(bt.gain * (qi - bt.a)));
+      } else {
+        h = fmin(h, dt * bt.a);
+        l = fmax(l, -(dt * bt.a));
+      }
+    }
+    if (!(l <= h)) status = 2;
+    double xi = fmin(fmax(-ci / hii, l), h);
+    double vi = xi / dt;
+    if (INTEGRATE) {
+      row[dd.qadr] = qi + dt * vi;
+      if (vrow) vrow[i] = vi;
+    } else {
+      row[i] = vi;
+    }
+  }
+  if (INTEGRATE) {
+    // mj_integratePos renormalises free-joint quaternions even at zero velocity.
+    for (int f = 0; f < D->nfree; ++f) {
+      double* qq = row + D->free_qadr[f] + 3;
+      Q4 nq = qnormalize(Q4{qq[0], qq[1], qq[2], qq[3]});
+      qq[0] = nq.w; qq[1] = nq.x; qq[2] = nq.y; qq[3] = nq.z;
+    }
+  }
+  return status;
+}
+
+// Coalesced copy between a [rows, width] global block and the per-lane LDS rows.
+template <bool TO_LDS>
+MK_DEV void tile_copy(double* tile, int stride, double* g, int rows, int width) {
+  const int lane = threadIdx.x;
+  int r = lane / width, cidx = lane % width;
+  const int dr = 64 / width, dc = 64 % width;
+  const int total = rows * width;
+  for (int i = lane; i < total; i += 64) {
+    if (TO_LDS) tile[r * stride + cidx] = g[i]; else g[i] = tile[r * stride + cidx];
+    r += dr;
+    cidx += dc;
+    if (cidx >= width) { cidx -= width; ++r; }
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(64) void fused_step_kernel(const MkFusedDesc* __restrict__ D,
+                                                        const double* __restrict__ q,
+                                                        const double* __restrict__ targets, int target_stride,
+                                                        double dt, double damping, int B,
+                                                        double* __restrict__ v_out, int32_t* __restrict__ status_out) {
+  extern __shared__ double tile[];
+  const int nq = D->nq, nv = D->nv;
+  const int stride = nq | 1;
+  const int lane = threadIdx.x;
+  const long base = (long)blockIdx.x * 64;
+  const int rows = (int)min((long)64, (long)B - base);
+  tile_copy<true>(tile, stride, const_cast<double*>(q) + base * nq, rows, nq);
+  __syncthreads();
+  const bool valid = lane < rows;
+  double* row = tile + lane * stride;
+  if (!valid) {
+    for (int i = 0; i < nq; ++i) row[i] = tile[i];
+  }
+  const long pb = valid ? base + lane : base;
+  const double* tg = targets + pb * target_stride + D->target_off;
+  Q4 Qt = Q4{tg[0], tg[1], tg[2], tg[3]};
+  V3 pt = v3(tg[4], tg[5], tg[6]);
+  double qc[NC], x[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) qc[k] = row[D->seg[k].qadr];
+  ChainFK<NC> fk;
+  chain_fk<NC>(D, qc, Qt, pt, fk);
+  int status = solve_problem<NC, false>(D, row, qc, fk, dt, damping, x, nullptr);
+#pragma unroll
+  for (int k = 0; k < NC; ++k)
+    if (D->seg[k].dof >= 0) row[D->seg[k].dof] = x[k] / dt;
+  if (valid) status_out[pb] = status;
+  __syncthreads();
+  tile_copy<false>(tile, stride, v_out + base * nv, rows, nv);
+}
+
+template <int NC>
+__global__ __launch_bounds__(64) void fused_iterate_kernel(const MkFusedDesc* __restrict__ D,
+                                                           double* __restrict__ q,
+                                                           const double* __restrict__ targets, int target_stride,
+                                                           double dt, double damping, int B, int max_iters,
+                                                           double pos_tol, double ori_tol,
+                                                           double* __restrict__ v_out, int32_t* __restrict__ iters_out,
+                                                           double* __restrict__ err_out,
+                                                           int32_t* __restrict__ status_out) {
+  extern __shared__ double tile[];
+  const int nq = D->nq, nv = D->nv;
+  const int stride = nq | 1;
+  const int lane = threadIdx.x;
+  const long base = (long)blockIdx.x * 64;
+  const int rows = (int)min((long)64, (long)B - base);
+  tile_copy<true>(tile, stride, q + base * nq, rows, nq);
+  __syncthreads();
+  const bool valid = lane < rows;
+  double* row = tile + lane * stride;
+  if (!valid) {
+    for (int i = 0; i < nq; ++i) row[i] = tile[i];
+  }
+  const long pb = valid ? base + lane : base;
+  const double* tg = targets + pb * target_stride + D->target_off;
+  Q4 Qt = Q4{tg[0], tg[1], tg[2], tg[3]};
+  V3 pt = v3(tg[4], tg[5], tg[6]);
+  double qc[NC], x[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) { qc[k] = row[D->seg[k].qadr]; x[k] = 0.0; }
+  Twist e = Twist{v3(0, 0, 0), v3(0, 0, 0)};
+  int status = 0, iters = 0;
+  bool done = false;
+  double* vrow = (valid && v_out) ? v_out + pb * nv : nullptr;
+  for (int it = 0; it <= max_iters; ++it) {
+    if (!done) {
+      ChainFK<NC> fk;
+      chain_fk<NC>(D, qc, Qt, pt, fk);
+      e = fk.e;
+      // exit test of the callers' loop, evaluated on the configuration reached by
+      // the previous solve (interactive_scripts/teleop_mouse.py:117-121)
+      const bool conv = it > 0 && sqrt(dot(e.v, e.v)) <= pos_tol && sqrt(dot(e.w, e.w)) <= ori_tol;
+      if (conv || it == max_iters) {
+        done = true;
+      } else {
+        int st = solve_problem<NC, true>(D, row, qc, fk, dt, damping, x, vrow);
+        status = max(status, st);
+        iters = it + 1;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          double vk = x[k] / dt;
+          x[k] = vk;
+          qc[k] = qc[k] + dt * vk;
+          if (D->seg[k].dof >= 0) row[D->seg[k].qadr] = qc[k];
+        }
+      }
+    }
+    if (mk_wave_none(!done)) break;
+  }
+  if (vrow) {
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+      if (D->seg[k].dof >= 0) vrow[D->seg[k].dof] = x[k];
+  }
+  if (valid) {
+    status_out[pb] = status;
+    if (iters_out) iters_out[pb] = iters;
+    if (err_out) {
+      double* eo = err_out + pb * 6;
+      eo[0] = e.v.x; eo[1] = e.v.y; eo[2] = e.v.z; eo[3] = e.w.x; eo[4] = e.w.y; eo[5] = e.w.z;
+    }
+  }
+  __syncthreads();
+  tile_copy<false>(tile, stride, q + base * nq, rows, nq);
+}
+
+}  // namespace
+
+// Host-side launchers (called from mk_api.hip).
+template <int NC>
+static hipError_t launch_step(const MkFusedDesc* d_desc, int nq, const double* q, const double* targets,
+                              int target_stride, double dt, double damping, int B, double* v, int32_t* status,
+                              hipStream_t stream) {
+  const int blocks = (B + 63) / 64;
+  const size_t lds = (size_t)64 * (nq | 1) * sizeof(double);
+  hipLaunchKernelGGL(fused_step_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, targets, target_stride,
+                     dt, damping, B, v, status);
+  return hipGetLastError();
+}
+
+template <int NC>
+static hipError_t launch_iterate(const MkFusedDesc* d_desc, int nq, double* q, const double* targets,
+                                 int target_stride, double dt, double damping, int B, int max_iters, double pos_tol,
+                                 double ori_tol, double* v, int32_t* iters, double* err, int32_t* status,
+                                 hipStream_t stream) {
+  const int blocks = (B + 63) / 64;
+  const size_t lds = (size_t)64 * (nq | 1) * sizeof(double);
+  hipLaunchKernelGGL(fused_iterate_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
+                     target_stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status);
+  return hipGetLastError();
+}
+
+hipError_t mk_fused_launch_step(int nc, const MkFusedDesc* d_desc, int nq, const double* q, const double* targets,
+                                int target_stride, double dt, double damping, int B, double* v, int32_t* status,
+                                hipStream_t stream) {
+  switch (nc) {
+#define MK_CASE(N) \
+  case N: return launch_step<N>(d_desc, nq, q, targets, target_stride, dt, damping, B, v, status, stream);
+    MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
+#undef MK_CASE
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, double* q, const double* targets,
+                                   int target_stride, double dt, double damping, int B, int max_iters,
+                                   double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
+                                   int32_t* status, hipStream_t stream) {
+  switch (nc) {
+#define MK_CASE(N)                                                                                         \
+  case N:                                                                                                  \
+    return launch_iterate<N>(d_desc, nq, q, targets, target_stride, dt, damping, B, max_iters, pos_tol,   \
+                             ori_tol, v, iters, err, status, stream);
+    MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
+#undef MK_CASE
+    default: return hipErrorInvalidValue;
+  }
+}

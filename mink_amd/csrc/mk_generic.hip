@@ -1,0 +1,184 @@
+// Generic utility kernels (see mk_generic.h).  They restate, per problem:
+//   mj_integratePos                     (mink/configuration.py:225,235)
+//   mj_kinematics + mj_jac for a frame   (mink/configuration.py:112-185)
+//   Configuration.check_limits          (mink/configuration.py:77-110)
+#include "mk_generic.h"
+
+#include "../../include/mink_amd.h"
+#include "mk_device.h"
+
+namespace {
+
+// q <- q (+) dt v, one thread per (problem, joint).
+__global__ void integrate_kernel(MkDevModel m, double* __restrict__ q, const double* __restrict__ v, double dt,
+                                 long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long b = idx / m.njnt;
+  const int j = (int)(idx - b * m.njnt);
+  double* qq = q + b * m.nq + m.jnt_qposadr[j];
+  const double* vv = v + b * m.nv + m.jnt_dofadr[j];
+  const int t = m.jnt_type[j];
+  if (t == MK_JNT_HINGE || t == MK_JNT_SLIDE) {
+    qq[0] += dt * vv[0];
+    return;
+  }
+  if (t == MK_JNT_FREE) {
+    qq[0] += dt * vv[0];
+    qq[1] += dt * vv[1];
+    qq[2] += dt * vv[2];
+    qq += 3;
+    vv += 3;
+  }
+  // mju_quatIntegrate: quat <- normalize(quat) * axisangle(w / |w|, dt |w|)
+  V3 w = v3(vv[0], vv[1], vv[2]);
+  double n = sqrt(dot(w, w));
+  V3 ax = n < MK_MINVAL ? v3(1, 0, 0) : (1.0 / n) * w;
+  if (n < MK_MINVAL) n = 0.0;
+  double ang = dt * n, sn, cs;
+  sincos(0.5 * ang, &sn, &cs);
+  Q4 rot = ang == 0.0 ? Q4{1, 0, 0, 0} : Q4{cs, sn * ax.x, sn * ax.y, sn * ax.z};
+  Q4 r = qmul(qnormalize(Q4{qq[0], qq[1], qq[2], qq[3]}), rot);
+  qq[0] = r.w; qq[1] = r.x; qq[2] = r.y; qq[3] = r.z;
+}
+
+struct BodyState {
+  V3 p;
+  Q4 Q;
+  M3 R;
+};
+
+// Advances (p, Q, R) from the parent frame through body `b`; when JAC, also emits the
+// body-frame Jacobian columns of this body's dofs for a frame at (ps, Rs).
+template <bool JAC>
+MK_DEV void advance_body(const MkDevModel& m, const double* __restrict__ q, int b, BodyState& st, V3 ps, const M3& Rs,
+                         double* __restrict__ jac) {
+  const int ja = m.body_jntadr[b], jn = m.body_jntnum[b];
+  const int nv = m.nv;
+  auto emit = [&](int dof, V3 lin, V3 ang) {
+    V3 bl = mulT(Rs, lin), ba = mulT(Rs, ang);
+    jac[0 * nv + dof] = bl.x; jac[1 * nv + dof] = bl.y; jac[2 * nv + dof] = bl.z;
+    jac[3 * nv + dof] = ba.x; jac[4 * nv + dof] = ba.y; jac[5 * nv + dof] = ba.z;
+  };
+  if (jn == 1 && m.jnt_type[ja] == MK_JNT_FREE) {
+    const double* qq = q + m.jnt_qposadr[ja];
+    st.p = v3(qq[0], qq[1], qq[2]);
+    st.Q = qnormalize(Q4{qq[3], qq[4], qq[5], qq[6]});
+    st.R = q2m(st.Q);
+    if (JAC) {
+      const int d0 = m.jnt_dofadr[ja];
+      emit(d0 + 0, v3(1, 0, 0), v3(0, 0, 0));
+      emit(d0 + 1, v3(0, 1, 0), v3(0, 0, 0));
+      emit(d0 + 2, v3(0, 0, 1), v3(0, 0, 0));
+      for (int k = 0; k < 3; ++k) {
+        V3 ax = v3(st.R.m[k], st.R.m[3 + k], st.R.m[6 + k]);
+        emit(d0 + 3 + k, cross(ax, ps - st.p), ax);
+      }
+    }
+    return;
+  }
+  st.p = st.p + mul(st.R, v3(m.body_pos[3 * b], m.body_pos[3 * b + 1], m.body_pos[3 * b + 2]));
+  st.Q = qmul(st.Q, Q4{m.body_quat[4 * b], m.body_quat[4 * b + 1], m.body_quat[4 * b + 2], m.body_quat[4 * b + 3]});
+  st.R = q2m(st.Q);
+  // ball-joint columns need the body's final orientation: remember them
+  int ball_dof = -1;
+  V3 ball_anchor = v3(0, 0, 0);
+  for (int j = ja; j < ja + jn; ++j) {
+    const int t = m.jnt_type[j];
+    const int qa = m.jnt_qposadr[j], d0 = m.jnt_dofadr[j];
+    V3 jpos = v3(m.jnt_pos[3 * j], m.jnt_pos[3 * j + 1], m.jnt_pos[3 * j + 2]);
+    V3 axl = v3(m.jnt_axis[3 * j], m.jnt_axis[3 * j + 1], m.jnt_axis[3 * j + 2]);
+    V3 ax = mul(st.R, axl);
+    V3 an = st.p + mul(st.R, jpos);
+    if (t == MK_JNT_SLIDE) {
+      st.p = st.p + (q[qa] - m.qpos0[qa]) * ax;
+      if (JAC) emit(d0, ax, v3(0, 0, 0));
+    } else {
+      Q4 ql;
+      if (t == MK_JNT_BALL) {
+        ql = qnormalize(Q4{q[qa], q[qa + 1], q[qa + 2], q[qa + 3]});
+        ball_dof = d0;
+        ball_anchor = an;
+      } else {
+        double sn, cs;
+        sincos(0.5 * (q[qa] - m.qpos0[qa]), &sn, &cs);
+        ql = Q4{cs, sn * axl.x, sn * axl.y, sn * axl.z};
+        if (JAC) emit(d0, cross(ax, ps - an), ax);
+      }
+      st.Q = qmul(st.Q, ql);
+      st.R = q2m(st.Q);
+      st.p = an - mul(st.R, jpos);
+    }
+  }
+  st.Q = qnormalize(st.Q);
+  st.R = q2m(st.Q);
+  if (JAC && ball_dof >= 0) {
+    for (int k = 0; k < 3; ++k) {
+      V3 ax = v3(st.R.m[k], st.R.m[3 + k], st.R.m[6 + k]);
+      emit(ball_dof + k, cross(ax, ps - ball_anchor), ax);
+    }
+  }
+}
+
+__global__ void frame_kernel(MkDevModel m, const double* __restrict__ q, int B, int body, V3 lpos, Q4 lquat,
+                             double* __restrict__ pose, double* __restrict__ jac) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* qb = q + b * m.nq;
+  const int adr = m.path_adr[body], len = m.path_len[body];
+  BodyState st{v3(0, 0, 0), Q4{1, 0, 0, 0}, M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}}};
+  M3 none{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+  for (int i = 0; i < len; ++i) advance_body<false>(m, qb, m.path_data[adr + i], st, v3(0, 0, 0), none, nullptr);
+  V3 ps = st.p + mul(st.R, lpos);
+  Q4 Qs = qmul(st.Q, lquat);
+  if (pose) {
+    double* o = pose + b * 7;
+    o[0] = Qs.w; o[1] = Qs.x; o[2] = Qs.y; o[3] = Qs.z; o[4] = ps.x; o[5] = ps.y; o[6] = ps.z;
+  }
+  if (jac) {
+    double* jb = jac + b * 6 * m.nv;
+    for (int i = 0; i < 6 * m.nv; ++i) jb[i] = 0.0;
+    M3 Rs = q2m(Qs);
+    BodyState s2{v3(0, 0, 0), Q4{1, 0, 0, 0}, M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}}};
+    for (int i = 0; i < len; ++i) advance_body<true>(m, qb, m.path_data[adr + i], s2, ps, Rs, jb);
+  }
+}
+
+__global__ void check_limits_kernel(MkDevModel m, const double* __restrict__ q, double tol, int B,
+                                    int32_t* __restrict__ first) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* qb = q + b * m.nq;
+  int bad = -1;
+  for (int j = 0; j < m.njnt; ++j) {
+    if (m.jnt_type[j] == MK_JNT_FREE || !m.jnt_limited[j]) continue;
+    const double val = qb[m.jnt_qposadr[j]];
+    if ((val < m.jnt_range[2 * j] - tol || val > m.jnt_range[2 * j + 1] + tol) && bad < 0) bad = j;
+  }
+  first[b] = bad;
+}
+
+}  // namespace
+
+hipError_t mk_generic_integrate(const MkDevModel& m, double* q, const double* v, double dt, int B, hipStream_t s) {
+  const long total = (long)B * m.njnt;
+  const int threads = 256;
+  hipLaunchKernelGGL(integrate_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0, s, m, q, v,
+                     dt, total);
+  return hipGetLastError();
+}
+
+hipError_t mk_generic_frame(const MkDevModel& m, const double* q, int B, int body, const double* lpos,
+                            const double* lquat, double* d_pose, double* d_jac, hipStream_t s) {
+  const int threads = 64;
+  hipLaunchKernelGGL(frame_kernel, dim3((B + threads - 1) / threads), dim3(threads), 0, s, m, q, B, body,
+                     V3{lpos[0], lpos[1], lpos[2]}, Q4{lquat[0], lquat[1], lquat[2], lquat[3]}, d_pose, d_jac);
+  return hipGetLastError();
+}
+
+hipError_t mk_generic_check_limits(const MkDevModel& m, const double* q, double tol, int B, int32_t* first,
+                                   hipStream_t s) {
+  const int threads = 256;
+  hipLaunchKernelGGL(check_limits_kernel, dim3((B + threads - 1) / threads), dim3(threads), 0, s, m, q, tol, B, first);
+  return hipGetLastError();
+}

@@ -1,0 +1,163 @@
+"""Thin object layer over the C ABI: device-resident model and problem handles and
+the batched solve / iterate / integrate / FK calls on torch ROCm tensors.
+
+This is plumbing shared by the mink-named host API (configuration.py, tasks.py,
+limits.py, solve_ik.py) and by bench.py; all arithmetic happens in the HIP kernels.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _check_tensor(t: torch.Tensor, shape, dtype, name: str) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f"{name} must be a torch tensor on the GPU")
+    if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous {dtype} tensor of shape {tuple(shape)}, "
+                         f"got {t.dtype} {tuple(t.shape)}")
+
+
+class DeviceModel:
+    """A kinematic tree uploaded to the current GPU (``mk_model``)."""
+
+    def __init__(self, model, device: Optional[torch.device] = None):
+        self.lib = L.load_library()
+        self.model = model
+        self.device = torch.device(device if device is not None else "cuda:0")
+        desc, keep = L.pack_model(model)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.mk_model_create(C.byref(desc), C.byref(handle)))
+        self.handle = handle
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            self.lib.mk_model_destroy(h)
+            self.handle = None
+
+    def integrate_(self, q: torch.Tensor, v: torch.Tensor, dt: float) -> None:
+        B = q.shape[0]
+        _check_tensor(q, (B, self.model.nq), torch.float64, "q")
+        _check_tensor(v, (B, self.model.nv), torch.float64, "v")
+        with torch.cuda.device(self.device):
+            L.check(self.lib.mk_integrate_batch(self.handle, q.data_ptr(), v.data_ptr(), float(dt), B,
+                                                _stream_ptr(self.device)))
+
+    def frame_pose(self, q: torch.Tensor, frame_type: int, frame_id: int) -> torch.Tensor:
+        B = q.shape[0]
+        _check_tensor(q, (B, self.model.nq), torch.float64, "q")
+        out = torch.empty((B, 7), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.mk_fk_batch(self.handle, q.data_ptr(), B, frame_type, frame_id, out.data_ptr(),
+                                         _stream_ptr(self.device)))
+        return out
+
+    def frame_jacobian(self, q: torch.Tensor, frame_type: int, frame_id: int) -> torch.Tensor:
+        B = q.shape[0]
+        _check_tensor(q, (B, self.model.nq), torch.float64, "q")
+        out = torch.empty((B, 6, self.model.nv), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.mk_frame_jacobian_batch(self.handle, q.data_ptr(), B, frame_type, frame_id,
+                                                     out.data_ptr(), _stream_ptr(self.device)))
+        return out
+
+    def first_limit_violation(self, q: torch.Tensor, tol: float) -> torch.Tensor:
+        B = q.shape[0]
+        _check_tensor(q, (B, self.model.nq), torch.float64, "q")
+        out = torch.empty((B,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.mk_check_limits_batch(self.handle, q.data_ptr(), float(tol), B, out.data_ptr(),
+                                                   _stream_ptr(self.device)))
+        return out
+
+
+class DeviceProblem:
+    """A task + limit set bound to a :class:`DeviceModel` (``mk_problem``)."""
+
+    def __init__(self, dmodel: DeviceModel, task_specs: Sequence[dict], limit_specs: Sequence[dict]):
+        self.lib = dmodel.lib
+        self.dmodel = dmodel
+        self.device = dmodel.device
+        ta, k1 = L.pack_tasks(task_specs)
+        la, k2 = L.pack_limits(limit_specs)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.mk_problem_create(dmodel.handle, ta, len(task_specs), la, len(limit_specs),
+                                               C.byref(handle)))
+        self.handle = handle
+        info = L.ProblemInfo()
+        L.check(self.lib.mk_problem_get_info(handle, C.byref(info)))
+        self.nq, self.nv = info.nq, info.nv
+        self.target_stride = info.target_stride
+        self.n_rows = info.n_rows
+        self.fused = bool(info.fused)
+        self.n_chain = info.n_chain
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            self.lib.mk_problem_destroy(h)
+            self.handle = None
+
+    def _targets_ptr(self, targets: Optional[torch.Tensor], B: int):
+        if self.target_stride == 0:
+            return None
+        _check_tensor(targets, (B, self.target_stride), torch.float64, "targets")
+        return targets.data_ptr()
+
+    def solve(self, q: torch.Tensor, targets: Optional[torch.Tensor], dt: float, damping: float,
+              v: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None):
+        B = q.shape[0]
+        _check_tensor(q, (B, self.nq), torch.float64, "q")
+        if v is None:
+            v = torch.empty((B, self.nv), dtype=torch.float64, device=self.device)
+        if status is None:
+            status = torch.empty((B,), dtype=torch.int32, device=self.device)
+        _check_tensor(v, (B, self.nv), torch.float64, "v")
+        _check_tensor(status, (B,), torch.int32, "status")
+        with torch.cuda.device(self.device):
+            L.check(self.lib.mk_solve_ik_batch(self.handle, q.data_ptr(), self._targets_ptr(targets, B), float(dt),
+                                               float(damping), B, v.data_ptr(), status.data_ptr(),
+                                               _stream_ptr(self.device)))
+        return v, status
+
+    def iterate_(self, q: torch.Tensor, targets: Optional[torch.Tensor], dt: float, damping: float, max_iters: int,
+                 pos_tol: float = -1.0, ori_tol: float = -1.0, want_v: bool = False, out: Optional[dict] = None):
+        """In-place loop on q. Returns dict(iters, err, status[, v])."""
+        B = q.shape[0]
+        _check_tensor(q, (B, self.nq), torch.float64, "q")
+        if out is None:
+            out = {}
+        iters = out.get("iters")
+        if iters is None:
+            iters = torch.empty((B,), dtype=torch.int32, device=self.device)
+        err = out.get("err")
+        if err is None:
+            err = torch.empty((B, 6), dtype=torch.float64, device=self.device)
+        status = out.get("status")
+        if status is None:
+            status = torch.empty((B,), dtype=torch.int32, device=self.device)
+        v = out.get("v")
+        if v is None and want_v:
+            v = torch.zeros((B, self.nv), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.mk_solve_ik_iterate_batch(
+                self.handle, q.data_ptr(), self._targets_ptr(targets, B), float(dt), float(damping), B,
+                int(max_iters), float(pos_tol), float(ori_tol), v.data_ptr() if v is not None else None,
+                iters.data_ptr(), err.data_ptr(), status.data_ptr(), _stream_ptr(self.device)))
+        res = dict(iters=iters, err=err, status=status)
+        if v is not None:
+            res["v"] = v
+        return res

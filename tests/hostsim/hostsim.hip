@@ -1,0 +1,123 @@
+// TEST-ONLY host build of the fused IK device functions.
+//
+// The product library (mink_amd/libmink_amd.so) runs solve_problem<NC>() inside HIP
+// kernels only.  This translation unit includes the same sources and calls the very
+// same templates lane by lane on the CPU, so the structured QP build / active-set
+// logic can be checked against the oracle in the CPU test suite (no GPU needed).
+// It is never loaded by the mink_amd package.
+#include "../../mink_amd/csrc/mk_api.hip"
+#include "../../mink_amd/csrc/mk_fused.hip"
+
+namespace {
+
+template <int NC>
+int run_step(const MkFusedDesc& D, const double* q, const double* targets, int stride, double dt, double damping,
+             int B, double* v, int32_t* status) {
+  std::vector<double> row(D.nq + 1);
+  for (int b = 0; b < B; ++b) {
+    memcpy(row.data(), q + (size_t)b * D.nq, D.nq * sizeof(double));
+    const double* tg = targets + (size_t)b * stride + D.target_off;
+    double qc[NC], x[NC];
+    for (int k = 0; k < NC; ++k) qc[k] = row[D.seg[k].qadr];
+    ChainFK<NC> fk;
+    chain_fk<NC>(&D, qc, Q4{tg[0], tg[1], tg[2], tg[3]}, v3(tg[4], tg[5], tg[6]), fk);
+    status[b] = solve_problem<NC, false>(&D, row.data(), qc, fk, dt, damping, x, nullptr);
+    for (int k = 0; k < NC; ++k)
+      if (D.seg[k].dof >= 0) row[D.seg[k].dof] = x[k] / dt;
+    memcpy(v + (size_t)b * D.nv, row.data(), D.nv * sizeof(double));
+  }
+  return 0;
+}
+
+template <int NC>
+int run_iterate(const MkFusedDesc& D, double* q, const double* targets, int stride, double dt, double damping, int B,
+                int max_iters, double pos_tol, double ori_tol, double* v, int32_t* iters_out, double* err,
+                int32_t* status_out) {
+  std::vector<double> row(D.nq + 1);
+  for (int b = 0; b < B; ++b) {
+    memcpy(row.data(), q + (size_t)b * D.nq, D.nq * sizeof(double));
+    const double* tg = targets + (size_t)b * stride + D.target_off;
+    Q4 Qt{tg[0], tg[1], tg[2], tg[3]};
+    V3 pt = v3(tg[4], tg[5], tg[6]);
+    double qc[NC], x[NC];
+    for (int k = 0; k < NC; ++k) { qc[k] = row[D.seg[k].qadr]; x[k] = 0.0; }
+    double* vrow = v ? v + (size_t)b * D.nv : nullptr;
+    Twist e{};
+    int status = 0, iters = 0;
+    for (int it = 0; it <= max_iters; ++it) {
+      ChainFK<NC> fk;
+      chain_fk<NC>(&D, qc, Qt, pt, fk);
+      e = fk.e;
+      const bool conv = it > 0 && sqrt(dot(e.v, e.v)) <= pos_tol && sqrt(dot(e.w, e.w)) <= ori_tol;
+      if (conv || it == max_iters) break;
+      int st = solve_problem<NC, true>(&D, row.data(), qc, fk, dt, damping, x, vrow);
+      status = std::max(status, st);
+      iters = it + 1;
+      for (int k = 0; k < NC; ++k) {
+        double vk = x[k] / dt;
+        x[k] = vk;
+        qc[k] = qc[k] + dt * vk;
+        if (D.seg[k].dof >= 0) row[D.seg[k].qadr] = qc[k];
+      }
+    }
+    if (vrow)
+      for (int k = 0; k < NC; ++k)
+        if (D.seg[k].dof >= 0) vrow[D.seg[k].dof] = x[k];
+    status_out[b] = status;
+    if (iters_out) iters_out[b] = iters;
+    if (err) {
+      double* eo = err + (size_t)b * 6;
+      eo[0] = e.v.x; eo[1] = e.v.y; eo[2] = e.v.z; eo[3] = e.w.x; eo[4] = e.w.y; eo[5] = e.w.z;
+    }
+    memcpy(q + (size_t)b * D.nq, row.data(), D.nq * sizeof(double));
+  }
+  return 0;
+}
+
+int build(const mk_model_desc* md, const mk_task_desc* tasks, int ntask, const mk_limit_desc* limits, int nlimit,
+          MkFusedDesc& D, int* nk, int* stride) {
+  HostModel h;
+  int rc = host_model_from_desc(md, h);
+  if (rc != MK_OK) return rc;
+  std::string why;
+  if (!build_fused(h, tasks, ntask, limits, nlimit, D, nk, why)) return fail(MK_ERR_UNSUPPORTED, "%s", why.c_str());
+  *stride = 0;
+  for (int t = 0; t < ntask; ++t)
+    *stride += (tasks[t].type == MK_TASK_FRAME || tasks[t].type == MK_TASK_RELATIVE_FRAME) ? 7
+               : tasks[t].type == MK_TASK_COM ? 3 : 0;
+  return MK_OK;
+}
+
+}  // namespace
+
+#define HS_DISPATCH(fn, ...)            \
+  switch (nk) {                         \
+    case 4: return fn<4>(__VA_ARGS__);  \
+    case 6: return fn<6>(__VA_ARGS__);  \
+    case 7: return fn<7>(__VA_ARGS__);  \
+    case 8: return fn<8>(__VA_ARGS__);  \
+    case 10: return fn<10>(__VA_ARGS__); \
+    case 12: return fn<12>(__VA_ARGS__); \
+    default: return MK_ERR_UNSUPPORTED; \
+  }
+
+extern "C" int hostsim_solve_ik(const mk_model_desc* md, const mk_task_desc* tasks, int ntask,
+                                const mk_limit_desc* limits, int nlimit, const double* q, const double* targets,
+                                double dt, double damping, int B, double* v, int32_t* status) {
+  static MkFusedDesc D;
+  int nk, stride;
+  int rc = build(md, tasks, ntask, limits, nlimit, D, &nk, &stride);
+  if (rc != MK_OK) return rc;
+  HS_DISPATCH(run_step, D, q, targets, stride, dt, damping, B, v, status)
+}
+
+extern "C" int hostsim_iterate(const mk_model_desc* md, const mk_task_desc* tasks, int ntask,
+                               const mk_limit_desc* limits, int nlimit, double* q, const double* targets, double dt,
+                               double damping, int B, int max_iters, double pos_tol, double ori_tol, double* v,
+                               int32_t* iters, double* err, int32_t* status) {
+  static MkFusedDesc D;
+  int nk, stride;
+  int rc = build(md, tasks, ntask, limits, nlimit, D, &nk, &stride);
+  if (rc != MK_OK) return rc;
+  HS_DISPATCH(run_iterate, D, q, targets, stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status)
+}

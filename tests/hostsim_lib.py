@@ -1,0 +1,69 @@
+"""Loader for the TEST-ONLY host build of the fused device functions
+(tests/hostsim/hostsim.hip).  Used by CPU tests to check the structured QP path
+lane by lane against the oracle without a GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from mink_amd import _lib as L
+
+PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "libhostsim.so")
+
+
+def available():
+    return os.path.exists(PATH)
+
+
+_h = None
+
+
+def _load():
+    global _h
+    if _h is None:
+        _h = C.CDLL(PATH)
+        _h.hostsim_solve_ik.restype = C.c_int
+        _h.hostsim_iterate.restype = C.c_int
+        _h.mk_last_error.restype = C.c_char_p
+    return _h
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def solve_ik(model, task_specs, limit_specs, q, targets, dt, damping):
+    h = _load()
+    md, k1 = L.pack_model(model)
+    ta, k2 = L.pack_tasks(task_specs)
+    la, k3 = L.pack_limits(limit_specs)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    targets = np.ascontiguousarray(targets, dtype=np.float64)
+    B = q.shape[0]
+    v = np.zeros((B, model.nv))
+    status = np.zeros(B, dtype=np.int32)
+    rc = h.hostsim_solve_ik(C.byref(md), ta, C.c_int(len(task_specs)), la, C.c_int(len(limit_specs)), _ptr(q),
+                            _ptr(targets), C.c_double(dt), C.c_double(damping), C.c_int(B), _ptr(v), _ptr(status))
+    if rc != 0:
+        raise RuntimeError(f"hostsim rc={rc}: {h.mk_last_error().decode()}")
+    return v, status
+
+
+def iterate(model, task_specs, limit_specs, q, targets, dt, damping, max_iters, pos_tol, ori_tol):
+    h = _load()
+    md, k1 = L.pack_model(model)
+    ta, k2 = L.pack_tasks(task_specs)
+    la, k3 = L.pack_limits(limit_specs)
+    q = np.array(q, dtype=np.float64, order="C")
+    targets = np.ascontiguousarray(targets, dtype=np.float64)
+    B = q.shape[0]
+    v = np.zeros((B, model.nv))
+    iters = np.zeros(B, dtype=np.int32)
+    err = np.zeros((B, 6))
+    status = np.zeros(B, dtype=np.int32)
+    rc = h.hostsim_iterate(C.byref(md), ta, C.c_int(len(task_specs)), la, C.c_int(len(limit_specs)), _ptr(q),
+                           _ptr(targets), C.c_double(dt), C.c_double(damping), C.c_int(B), C.c_int(max_iters),
+                           C.c_double(pos_tol), C.c_double(ori_tol), _ptr(v), _ptr(iters), _ptr(err), _ptr(status))
+    if rc != 0:
+        raise RuntimeError(f"hostsim rc={rc}: {h.mk_last_error().decode()}")
+    return q, v, iters, err, status
