@@ -14,7 +14,8 @@ from typing import List, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmink_amd.so")
+# MINK_AMD_LIB lets kernel-tuning scripts load an experimental build of the same library.
+LIB_PATH = os.environ.get("MINK_AMD_LIB") or os.path.join(_HERE, "libmink_amd.so")
 
 MK_OK, MK_ERR_INVALID, MK_ERR_UNSUPPORTED, MK_ERR_HIP = 0, -1, -2, -3
 FRAME_TYPES = {"body": 0, "geom": 1, "site": 2}

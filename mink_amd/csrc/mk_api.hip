@@ -186,6 +186,7 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
     const int a = m.jnt_dofadr[j], qa = m.jnt_qposadr[j];
     if (m.jnt_type[j] == MK_JNT_FREE) {
       if (D.nfree >= 8) { why = "too many free joints"; return false; }
+      D.free_dofadr[D.nfree] = a;
       D.free_qadr[D.nfree++] = qa;
       for (int k = 0; k < 6; ++k) {
         D.dof[a + k].qadr = qa + (k < 3 ? k : 3);
@@ -295,6 +296,47 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
         if (!add_term(dof, bt)) { why = "too many limits on one dof"; return false; }
       }
     }
+  }
+  // packed per-dof constants (what the kernels read on the lm_damping == 0 path)
+  auto pack = [&](int dof, MkDofC& c) -> bool {
+    const MkDof& dd = D.dof[dof];
+    c.A = c.B = c.W = 0.0;
+    c.lower = -INFINITY; c.upper = INFINITY; c.gain = 1.0; c.vmax = INFINITY;
+    c.qadr = dd.qadr;
+    c.dof = dof;
+    for (int t = 0; t < D.nposture; ++t) {
+      const MkPosture& P = D.posture[t];
+      const double w = P.cost[dof] * P.cost[dof];
+      c.A += P.gain * w * P.target[dof];
+      c.B += P.gain * w;
+      c.W += w;
+    }
+    bool has_cfg = false, has_vel = false;
+    for (int t = 0; t < dd.nterm; ++t) {
+      const MkBoundTerm& bt = dd.term[t];
+      if (bt.kind == MK_TERM_CFG) {
+        if (has_cfg) return false;
+        has_cfg = true;
+        c.lower = bt.a; c.upper = bt.b; c.gain = bt.gain;
+      } else {
+        if (has_vel) { c.vmax = std::min(c.vmax, bt.a); continue; }
+        has_vel = true;
+        c.vmax = bt.a;
+      }
+    }
+    return true;
+  };
+  D.nd = 0;
+  D.any_posture_lm = 0;
+  for (int t = 0; t < D.nposture; ++t)
+    if (D.posture[t].lm > 0.0) D.any_posture_lm = 1;
+  for (int k = 0; k < nk; ++k) {
+    if (D.seg[k].dof < 0) { memset(&D.sdof[k], 0, sizeof(MkDofC)); D.sdof[k].dof = -1; continue; }
+    if (!pack(D.seg[k].dof, D.sdof[k])) { why = "several configuration limits on one dof"; return false; }
+  }
+  for (int i = 0; i < m.nv; ++i) {
+    if (D.dof[i].slot >= 0 || D.dof[i].kind != MK_DOF_SCALAR) continue;
+    if (!pack(i, D.ddof[D.nd++])) { why = "several configuration limits on one dof"; return false; }
   }
   return true;
 }

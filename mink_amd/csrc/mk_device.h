@@ -56,6 +56,15 @@ struct MkDof {
   MkBoundTerm term[MK_MAX_TERMS];
 };
 
+// Constants of one scalar dof, packed into one 64-byte record (a single scalar load):
+// the sum of the posture-like tasks on it and its box limits.
+struct MkDofC {
+  double A, B, W;             // c_i = B * q_i - A,  H_ii += W   (sums over posture tasks)
+  double lower, upper, gain;  // ConfigurationLimit (-inf / +inf / 1 when absent)
+  double vmax;                // VelocityLimit (+inf when absent)
+  int32_t qadr, dof;          // dof < 0: padding slot
+};
+
 struct MkPosture {
   double gain, lm;
   double cost[MK_MAX_NV];     // per dof (free-joint dofs forced to 0)
@@ -69,14 +78,36 @@ struct MkFusedDesc {
   MkSeg seg[MK_MAX_CHAIN];
   double post_pos[3], post_quat[4];   // last chain body -> task frame
   double cost[6], gain, lm;           // frame task
-  MkPosture posture[MK_MAX_POSTURE];
+  MkPosture posture[MK_MAX_POSTURE];   // only read when a posture task has lm_damping > 0
   MkDof dof[MK_MAX_NV];
+  int32_t nd, any_posture_lm;
+  int32_t free_dofadr[8];
+  MkDofC sdof[MK_MAX_CHAIN];           // chain dofs, by slot
+  MkDofC ddof[MK_MAX_NV];              // scalar dofs outside the chain, increasing dof order
 };
 
 // ------------------------------------------------------------------ math ----
+// Reciprocal / reciprocal square root for normal-range positive-scale arguments:
+// hardware seed (v_rcp_f64 / v_rsq_f64) plus two Newton steps, ~1 ulp, without the
+// scaling and fix-up sequence of a full IEEE division (the operands here are norms,
+// Cholesky pivots, dt and Hessian diagonals, never denormal or infinite).
+MK_DEV double mk_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
 MK_DEV double mk_rsqrt(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return rsqrt(x);
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = fma(fma(-hx * y, y, 0.5), y, y);
+  y = fma(fma(-hx * y, y, 0.5), y, y);
+  return y;
 #else
   return 1.0 / sqrt(x);
 #endif
@@ -115,9 +146,10 @@ MK_DEV Q4 qconj(Q4 a) { return Q4{a.w, -a.x, -a.y, -a.z}; }
 
 // mju_normalize4: a vanishing quaternion maps to identity.
 MK_DEV Q4 qnormalize(Q4 q) {
-  double n = sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-  if (n < MK_MINVAL) return Q4{1.0, 0.0, 0.0, 0.0};
-  return Q4{q.w / n, q.x / n, q.y / n, q.z / n};
+  const double n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+  if (n2 < MK_MINVAL * MK_MINVAL) return Q4{1.0, 0.0, 0.0, 0.0};
+  const double r = mk_rsqrt(n2);
+  return Q4{q.w * r, q.x * r, q.y * r, q.z * r};
 }
 
 // mju_quat2Mat.

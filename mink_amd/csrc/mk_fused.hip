@@ -18,32 +18,56 @@
 // active sets run one instruction stream.
 #include "mk_device.h"
 
+// One wave per workgroup; register budget / occupancy target of the fused kernels.
+#ifndef MK_KERNEL_ATTR
+#define MK_KERNEL_ATTR __launch_bounds__(64)
+#endif
+
 namespace {
 
+// Optional instrumentation of the host test build only (never in device code).
+#if defined(MK_QP_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+static long g_qp_stats[4];  // solves, phase-1 rounds, phase-2 steps, factorizations
+#define MK_STAT(i) (++g_qp_stats[i])
+#else
+#define MK_STAT(i) ((void)0)
+#endif
+
 MK_DEV constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+// Read-only view of a packed lower-triangular matrix with a per-lane stride: on the
+// GPU the Hessian of each lane lives in LDS as element e of lane l at p[e * 64 + l]
+// (conflict-free b64 reads, compile-time offsets); the host test build uses stride 1.
+struct HView {
+  const double* p;
+  int stride;
+  MK_DEV double operator()(int e) const { return p[e * stride]; }
+};
 
 // Cholesky factor of H with the rows/columns in `act` replaced by identity.
 // L holds the strict lower triangle, Ld the reciprocals of the diagonal.
 template <int N>
-MK_DEV void chol_masked(const double (&H)[N * (N + 1) / 2], uint32_t act, double (&L)[N * (N + 1) / 2],
-                        double (&Ld)[N]) {
+MK_DEV void chol_masked(HView H, uint32_t act, double (&L)[N * (N + 1) / 2], double (&Ld)[N]) {
+  MK_STAT(3);
   double mk[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) mk[i] = ((act >> i) & 1u) ? 0.0 : 1.0;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    double s = mk[j] * H[tri(j, j)] + (1.0 - mk[j]);
+    double s = mk[j] * H(tri(j, j)) + (1.0 - mk[j]);
 #pragma unroll
     for (int k = 0; k < j; ++k) s -= L[tri(j, k)] * L[tri(j, k)];
     s = fmax(s, 1e-300);
-    double r = mk_rsqrt(s);
+    const double r = mk_rsqrt(s);
     Ld[j] = r;
+    const double rm = r * mk[j];   // a masked column is zero below its unit diagonal
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {
-      double t = (mk[i] * mk[j]) * H[tri(i, j)];
+      // rows of masked variables are zero: L[i][k] = 0 for k < j, so only the H term needs mk[i]
+      double t = H(tri(i, j)) * mk[i];
 #pragma unroll
       for (int k = 0; k < j; ++k) t -= L[tri(i, k)] * L[tri(j, k)];
-      L[tri(i, j)] = t * r;
+      L[tri(i, j)] = t * rm;
     }
   }
 }
@@ -67,73 +91,145 @@ MK_DEV void chol_solve(const double (&L)[N * (N + 1) / 2], const double (&Ld)[N]
   }
 }
 
-// min 1/2 x'Hx + c'x  s.t. lo <= x <= hi, H positive definite (dense N x N).
-// Dual active-set method: start from the unconstrained minimiser; pick the most
-// violated bound p; move along the direction that keeps the active bounds tight
-// until p is satisfied (full step) or a multiplier reaches zero (partial step: that
-// bound leaves the active set).  Returns 0 ok / 1 iteration limit / 2 infeasible.
+// y = H x for the packed symmetric H, reading every stored entry once.
 template <int N>
-MK_DEV int box_qp(const double (&H)[N * (N + 1) / 2], const double (&c)[N], const double (&lo)[N],
-                  const double (&hi)[N], double (&x)[N]) {
+MK_DEV void symv(HView H, const double (&x)[N], double (&y)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) y[i] = H(tri(i, i)) * x[i];
+#pragma unroll
+  for (int i = 1; i < N; ++i) {
+#pragma unroll
+    for (int j = 0; j < i; ++j) {
+      const double h = H(tri(i, j));
+      y[i] += h * x[j];
+      y[j] += h * x[i];
+    }
+  }
+}
+
+// min 1/2 x'Hx + c'x  s.t. lo <= x <= hi, H positive definite (dense N x N).
+//
+// Active-set method on lane masks, exact for strictly convex problems.  An "S-pair" is
+// an active set A with x the minimiser on the face {x_A at its bounds} and multipliers
+// u_A >= 0.
+//   phase 1  starts from a guess of A ({} cold, or the active set of the previous IK
+//            step of the same problem when warm) and repeats: solve on the face, drop
+//            every bound whose multiplier is negative and (for the first few rounds)
+//            add every violated bound.  A round that changes nothing has found the
+//            optimum outright.  After kGuessRounds the additions stop, so the set only
+//            shrinks and ends in an S-pair.
+//   phase 2  is the Goldfarb-Idnani dual method from that S-pair: pick the most violated
+//            inactive bound p and move along the direction that keeps A tight until p
+//            is satisfied (full step: p joins A) or a multiplier reaches zero (partial
+//            step: that bound leaves A).  It terminates for any strictly convex problem.
+// Every change of A refactors H with the rows/columns of A replaced by identity,
+// which keeps 64 different active sets on one instruction stream.
+// act/upper: in = guess (used when warm), out = final active set and its sides.
+// Returns 0 ok / 1 iteration limit / 2 infeasible.
+template <int N>
+MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const double (&hi)[N], double (&x)[N],
+                  uint32_t& act_io, uint32_t& upper_io, bool warm) {
+  constexpr double kTol = 1e-14;
+  constexpr int kGuessRounds = 6;
+  MK_STAT(0);
   double L[N * (N + 1) / 2], Ld[N];
   double u[N];
-  uint32_t act = 0u, upper = 0u;
+  uint32_t act = 0u, upper = upper_io;
   bool bad = false;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     u[i] = 0.0;
     bad |= !(lo[i] <= hi[i]);
   }
-  chol_masked<N>(H, 0u, L, Ld);
+  if (warm) {
+    act = act_io;
 #pragma unroll
-  for (int i = 0; i < N; ++i) x[i] = -c[i];
-  chol_solve<N>(L, Ld, x);
-
+    for (int i = 0; i < N; ++i) {
+      const double b = ((upper >> i) & 1u) ? hi[i] : lo[i];
+      if (!(fabs(b) < INFINITY)) act &= ~(1u << i);
+    }
+  }
+  // ---- phase 1 ----
+  bool settled = bad;
+  for (int round = 0; round < kGuessRounds + N + 2; ++round) {
+    if (!settled) {
+      MK_STAT(1);
+      // H is re-read from LDS every round on purpose: hoisting the loads would pin the
+      // whole matrix in registers next to the factor
+      asm volatile("" ::: "memory");
+      chol_masked<N>(H, act, L, Ld);
+      double xa[N], hx[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        xa[i] = ((act >> i) & 1u) ? (((upper >> i) & 1u) ? hi[i] : lo[i]) : 0.0;
+      symv<N>(H, xa, hx);
+#pragma unroll
+      for (int i = 0; i < N; ++i) x[i] = ((act >> i) & 1u) ? xa[i] : -c[i] - hx[i];
+      chol_solve<N>(L, Ld, x);
+      symv<N>(H, x, hx);
+      uint32_t drop = 0u, add = 0u, add_up = 0u;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const double g = c[i] + hx[i];
+        const bool a = (act >> i) & 1u;
+        const double ui = ((upper >> i) & 1u) ? -g : g;
+        u[i] = (a && ui > 0.0) ? ui : 0.0;
+        if (a && ui < 0.0) drop |= (1u << i);
+        if (!a && x[i] - hi[i] > kTol) { add |= (1u << i); add_up |= (1u << i); }
+        if (!a && lo[i] - x[i] > kTol) add |= (1u << i);
+      }
+      if (round >= kGuessRounds) add = 0u;
+      if ((drop | add) == 0u) {
+        settled = true;
+      } else {
+        act = (act & ~drop) | add;
+        upper = (upper & ~add) | (add_up & add);
+      }
+    }
+    if (mk_wave_none(!settled)) break;
+  }
+  // ---- phase 2 (L is valid for `act` here) ----
   int status = bad ? 2 : 0;
   bool done = bad;
   int p = -1;
   double sgn = 0.0, bound = 0.0, up_new = 0.0;
   for (int it = 0; it < 6 * N + 8; ++it) {
-    if (!done) {
-      if (p < 0) {
-        double worst = 1e-14;
+    if (!done && p < 0) {
+      double worst = kTol;
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-          bool free_i = !((act >> i) & 1u);
-          double vh = x[i] - hi[i], vl = lo[i] - x[i];
-          if (free_i && vh > worst) { worst = vh; p = i; sgn = 1.0; bound = hi[i]; }
-          if (free_i && vl > worst) { worst = vl; p = i; sgn = -1.0; bound = lo[i]; }
-        }
-        up_new = 0.0;
-        if (p < 0) done = true;
+      for (int i = 0; i < N; ++i) {
+        const bool free_i = !((act >> i) & 1u);
+        const double vh = x[i] - hi[i], vl = lo[i] - x[i];
+        if (free_i && vh > worst) { worst = vh; p = i; sgn = 1.0; bound = hi[i]; }
+        if (free_i && vl > worst) { worst = vl; p = i; sgn = -1.0; bound = lo[i]; }
       }
+      up_new = 0.0;
+      if (p < 0) done = true;
     }
     if (mk_wave_none(!done)) break;
     if (!done) {
-      chol_masked<N>(H, act, L, Ld);
-      double z[N];
+      MK_STAT(2);
+      asm volatile("" ::: "memory");
+      double z[N], r[N];
 #pragma unroll
       for (int i = 0; i < N; ++i) z[i] = (i == p) ? -sgn : 0.0;
       chol_solve<N>(L, Ld, z);
+      symv<N>(H, z, r);
       // dual step direction of the active bounds and the blocking one
       double t1 = INFINITY;
       int kb = -1;
       double xp = 0.0, zp = 0.0;
-      double r[N];
 #pragma unroll
       for (int k = 0; k < N; ++k) {
-        double hz = 0.0;
-#pragma unroll
-        for (int j = 0; j < N; ++j) hz += H[tri(k, j)] * z[j];
         const bool a = (act >> k) & 1u;
-        r[k] = ((upper >> k) & 1u) ? hz : -hz;
+        r[k] = ((upper >> k) & 1u) ? r[k] : -r[k];
         if (a && r[k] > 0.0) {
-          double t = u[k] / r[k];
+          double t = u[k] * mk_rcp(r[k]);
           if (t < t1) { t1 = t; kb = k; }
         }
         if (k == p) { xp = x[k]; zp = z[k]; }
       }
-      const double t2 = (bound - xp) / zp;
+      const double t2 = (bound - xp) * mk_rcp(zp);
       const bool full = t2 <= t1;
       const double t = full ? t2 : t1;
       up_new += t;
@@ -152,9 +248,12 @@ MK_DEV int box_qp(const double (&H)[N * (N + 1) / 2], const double (&c)[N], cons
       } else {
         act &= ~(1u << kb);
       }
+      chol_masked<N>(H, act, L, Ld);
     }
   }
   if (!done) status = 1;
+  act_io = act;
+  upper_io = upper;
   return status;
 }
 
@@ -224,7 +323,9 @@ MK_DEV void chain_fk(const MkFusedDesc* __restrict__ D, const double (&qc)[NC], 
 //                       velocity goes to vrow[dof] when vrow is not null
 template <int NC, bool INTEGRATE>
 MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const double (&qc)[NC],
-                         const ChainFK<NC>& fk, double dt, double damping, double (&x)[NC], double* vrow) {
+                         const ChainFK<NC>& fk, double dt, double inv_dt, double damping, double (&x)[NC],
+                         double* vrow, uint32_t& act, uint32_t& upper, bool warm, double* hstore,
+                         int hstride) {
   const Twist e = fk.e;
   const V3 ps = fk.ps;
   const M3 Rs = fk.Rs;
@@ -256,17 +357,19 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
                   cost[3] * (-g * e.w.x), cost[4] * (-g * e.w.y), cost[5] * (-g * e.w.z)};
   double diag = damping + D->lm * (ew[0] * ew[0] + ew[1] * ew[1] + ew[2] * ew[2] + ew[3] * ew[3] +
                                    ew[4] * ew[4] + ew[5] * ew[5]);
-  // Levenberg-Marquardt terms of posture tasks need the error over every dof.
-  for (int t = 0; t < D->nposture; ++t) {
-    const MkPosture& P = D->posture[t];
-    if (P.lm > 0.0) {
-      double s2 = 0.0;
-      for (int i = 0; i < D->nv; ++i) {
-        if (D->dof[i].kind != MK_DOF_SCALAR) continue;
-        double ewi = P.cost[i] * (-P.gain * (P.target[i] - row[D->dof[i].qadr]));
-        s2 += ewi * ewi;
+  // Levenberg-Marquardt terms of posture tasks need the error over every dof (rare).
+  if (D->any_posture_lm) {
+    for (int t = 0; t < D->nposture; ++t) {
+      const MkPosture& P = D->posture[t];
+      if (P.lm > 0.0) {
+        double s2 = 0.0;
+        for (int i = 0; i < D->nv; ++i) {
+          if (D->dof[i].kind != MK_DOF_SCALAR) continue;
+          double ewi = P.cost[i] * (-P.gain * (P.target[i] - row[D->dof[i].qadr]));
+          s2 += ewi * ewi;
+        }
+        diag += P.lm * s2;
       }
-      diag += P.lm * s2;
     }
   }
 
@@ -287,79 +390,62 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
   }
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
-    const int dofk = D->seg[k].dof;
-    if (dofk < 0) {  // padding slot: decoupled unit entry, solution 0
+    const MkDofC& dc = D->sdof[k];
+    if (dc.dof < 0) {  // padding slot: decoupled unit entry, solution 0
       H[tri(k, k)] = 1.0;
       c[k] = 0.0;
       lo[k] = -INFINITY;
       hi[k] = INFINITY;
       continue;
     }
-    double hkk = H[tri(k, k)] + diag;
-    double ck = c[k];
-    for (int t = 0; t < D->nposture; ++t) {
-      const MkPosture& P = D->posture[t];
-      double cst = P.cost[dofk];
-      double ewi = cst * (-P.gain * (P.target[dofk] - qc[k]));
-      hkk += cst * cst;
-      ck += ewi * cst;
-    }
-    H[tri(k, k)] = hkk;
-    c[k] = ck;
-    const MkDof& dd = D->dof[dofk];
-    double l = -INFINITY, h = INFINITY;
-    for (int t = 0; t < dd.nterm; ++t) {
-      const MkBoundTerm& bt = dd.term[t];
-      if (bt.kind == MK_TERM_CFG) {
-        h = fmin(h, bt.gain * (bt.b - qc[k]));
-        l = fmax(l, -(bt.gain * (qc[k] - bt.a)));
-      } else {
-        h = fmin(h, dt * bt.a);
-        l = fmax(l, -(dt * bt.a));
-      }
-    }
-    lo[k] = l;
-    hi[k] = h;
+    H[tri(k, k)] += diag + dc.W;
+    c[k] += dc.B * qc[k] - dc.A;
+    const double vb = dt * dc.vmax;
+    hi[k] = fmin(dc.gain * (dc.upper - qc[k]), vb);
+    lo[k] = fmax(-(dc.gain * (qc[k] - dc.lower)), -vb);
   }
 
-  int status = box_qp<NC>(H, c, lo, hi, x);
+#if defined(MK_ABLATE) && MK_ABLATE == 2
+  // tuning build only: skip the QP, keep the assembled H / c / bounds alive
+  int status = 0;
+  {
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < NC * (NC + 1) / 2; ++i) acc += H[i];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) x[i] = fmin(fmax(-c[i] * 1e-3 + 1e-30 * acc, lo[i]), hi[i]);
+  }
+#else
+  // park the Hessian in the lane's LDS column: the solver re-reads it, the registers are
+  // needed for the factor
+#pragma unroll
+  for (int i = 0; i < NC * (NC + 1) / 2; ++i) hstore[i * hstride] = H[i];
+  // keep the compiler from forwarding the stores back into registers
+  asm volatile("" ::: "memory");
+  int status = box_qp<NC>(HView{hstore, hstride}, c, lo, hi, x, act, upper, warm);
+#endif
 
   // ---- dofs outside the chain: diagonal Hessian, box limits -> clamp ----
-  for (int i = 0; i < D->nv; ++i) {
-    const MkDof& dd = D->dof[i];
-    if (dd.slot >= 0) continue;
-    if (dd.kind != MK_DOF_SCALAR) {
-      if (!INTEGRATE) row[i] = 0.0; else if (vrow) vrow[i] = 0.0;
-      continue;
-    }
-    const double qi = row[dd.qadr];
-    double hii = diag, ci = 0.0;
-    for (int t = 0; t < D->nposture; ++t) {
-      const MkPosture& P = D->posture[t];
-      double cst = P.cost[i];
-      double ewi = cst * (-P.gain * (P.target[i] - qi));
-      hii += cst * cst;
-      ci += ewi * cst;
-    }
-    double l = -INFINITY, h = INFINITY;
-    for (int t = 0; t < dd.nterm; ++t) {
-      const MkBoundTerm& bt = dd.term[t];
-      if (bt.kind == MK_TERM_CFG) {
-        h = fmin(h, bt.gain * (bt.b - qi));
-        l = fmax(l, -(bt.gain * (qi - bt.a)));
-      } else {
-        h = fmin(h, dt * bt.a);
-        l = fmax(l, -(dt * bt.a));
-      }
-    }
+  for (int d = 0; d < D->nd; ++d) {
+    const MkDofC& dc = D->ddof[d];
+    const double qi = row[dc.qadr];
+    const double vb = dt * dc.vmax;
+    const double h = fmin(dc.gain * (dc.upper - qi), vb);
+    const double l = fmax(-(dc.gain * (qi - dc.lower)), -vb);
     if (!(l <= h)) status = 2;
-    double xi = fmin(fmax(-ci / hii, l), h);
-    double vi = xi / dt;
+    const double xi = fmin(fmax(-(dc.B * qi - dc.A) * mk_rcp(diag + dc.W), l), h);
+    const double vi = xi * inv_dt;
     if (INTEGRATE) {
-      row[dd.qadr] = qi + dt * vi;
-      if (vrow) vrow[i] = vi;
+      row[dc.qadr] = qi + dt * vi;
+      if (vrow) vrow[dc.dof] = vi;
     } else {
-      row[i] = vi;
+      row[dc.dof] = vi;
+    }
+  }
+  // free-joint dofs: zero Jacobian columns and zeroed posture rows -> v = 0
+  for (int f = 0; f < D->nfree; ++f) {
+    for (int k = 0; k < 6; ++k) {
+      if (!INTEGRATE) row[D->free_dofadr[f] + k] = 0.0; else if (vrow) vrow[D->free_dofadr[f] + k] = 0.0;
     }
   }
   if (INTEGRATE) {
@@ -389,7 +475,7 @@ MK_DEV void tile_copy(double* tile, int stride, double* g, int rows, int width) 
 }
 
 template <int NC>
-__global__ __launch_bounds__(64) void fused_step_kernel(const MkFusedDesc* __restrict__ D,
+__global__ MK_KERNEL_ATTR void fused_step_kernel(const MkFusedDesc* __restrict__ D,
                                                         const double* __restrict__ q,
                                                         const double* __restrict__ targets, int target_stride,
                                                         double dt, double damping, int B,
@@ -397,6 +483,7 @@ __global__ __launch_bounds__(64) void fused_step_kernel(const MkFusedDesc* __res
   extern __shared__ double tile[];
   const int nq = D->nq, nv = D->nv;
   const int stride = nq | 1;
+  const double inv_dt = 1.0 / dt;
   const int lane = threadIdx.x;
   const long base = (long)blockIdx.x * 64;
   const int rows = (int)min((long)64, (long)B - base);
@@ -404,6 +491,7 @@ __global__ __launch_bounds__(64) void fused_step_kernel(const MkFusedDesc* __res
   __syncthreads();
   const bool valid = lane < rows;
   double* row = tile + lane * stride;
+  double* hlds = tile + 64 * stride + lane;   // packed Hessian, element e at hlds[e * 64]
   if (!valid) {
     for (int i = 0; i < nq; ++i) row[i] = tile[i];
   }
@@ -416,17 +504,19 @@ __global__ __launch_bounds__(64) void fused_step_kernel(const MkFusedDesc* __res
   for (int k = 0; k < NC; ++k) qc[k] = row[D->seg[k].qadr];
   ChainFK<NC> fk;
   chain_fk<NC>(D, qc, Qt, pt, fk);
-  int status = solve_problem<NC, false>(D, row, qc, fk, dt, damping, x, nullptr);
+  uint32_t act = 0u, upper = 0u;
+  int status = solve_problem<NC, false>(D, row, qc, fk, dt, inv_dt, damping, x, nullptr, act, upper, false,
+                                        hlds, 64);
 #pragma unroll
   for (int k = 0; k < NC; ++k)
-    if (D->seg[k].dof >= 0) row[D->seg[k].dof] = x[k] / dt;
+    if (D->seg[k].dof >= 0) row[D->seg[k].dof] = x[k] * inv_dt;
   if (valid) status_out[pb] = status;
   __syncthreads();
   tile_copy<false>(tile, stride, v_out + base * nv, rows, nv);
 }
 
 template <int NC>
-__global__ __launch_bounds__(64) void fused_iterate_kernel(const MkFusedDesc* __restrict__ D,
+__global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restrict__ D,
                                                            double* __restrict__ q,
                                                            const double* __restrict__ targets, int target_stride,
                                                            double dt, double damping, int B, int max_iters,
@@ -437,6 +527,7 @@ __global__ __launch_bounds__(64) void fused_iterate_kernel(const MkFusedDesc* __
   extern __shared__ double tile[];
   const int nq = D->nq, nv = D->nv;
   const int stride = nq | 1;
+  const double inv_dt = 1.0 / dt;
   const int lane = threadIdx.x;
   const long base = (long)blockIdx.x * 64;
   const int rows = (int)min((long)64, (long)B - base);
@@ -444,6 +535,7 @@ __global__ __launch_bounds__(64) void fused_iterate_kernel(const MkFusedDesc* __
   __syncthreads();
   const bool valid = lane < rows;
   double* row = tile + lane * stride;
+  double* hlds = tile + 64 * stride + lane;   // packed Hessian, element e at hlds[e * 64]
   if (!valid) {
     for (int i = 0; i < nq; ++i) row[i] = tile[i];
   }
@@ -457,6 +549,7 @@ __global__ __launch_bounds__(64) void fused_iterate_kernel(const MkFusedDesc* __
   Twist e = Twist{v3(0, 0, 0), v3(0, 0, 0)};
   int status = 0, iters = 0;
   bool done = false;
+  uint32_t act = 0u, upper = 0u;  // active bounds of the previous step: warm start of the next
   double* vrow = (valid && v_out) ? v_out + pb * nv : nullptr;
   for (int it = 0; it <= max_iters; ++it) {
     if (!done) {
@@ -469,12 +562,19 @@ __global__ __launch_bounds__(64) void fused_iterate_kernel(const MkFusedDesc* __
       if (conv || it == max_iters) {
         done = true;
       } else {
-        int st = solve_problem<NC, true>(D, row, qc, fk, dt, damping, x, vrow);
+#if defined(MK_ABLATE) && MK_ABLATE == 1
+        // tuning build only: forward kinematics + error, no QP build / solve
+        int st = 0;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) x[k] = 1e-4 * (fk.e.v.x + fk.e.w.y + fk.anchor[k].x + fk.axw[k].y);
+#else
+        int st = solve_problem<NC, true>(D, row, qc, fk, dt, inv_dt, damping, x, vrow, act, upper, it > 0, hlds, 64);
+#endif
         status = max(status, st);
         iters = it + 1;
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
-          double vk = x[k] / dt;
+          double vk = x[k] * inv_dt;
           x[k] = vk;
           qc[k] = qc[k] + dt * vk;
           if (D->seg[k].dof >= 0) row[D->seg[k].qadr] = qc[k];
@@ -508,7 +608,7 @@ static hipError_t launch_step(const MkFusedDesc* d_desc, int nq, const double* q
                               int target_stride, double dt, double damping, int B, double* v, int32_t* status,
                               hipStream_t stream) {
   const int blocks = (B + 63) / 64;
-  const size_t lds = (size_t)64 * (nq | 1) * sizeof(double);
+  const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
   hipLaunchKernelGGL(fused_step_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, targets, target_stride,
                      dt, damping, B, v, status);
   return hipGetLastError();
@@ -520,7 +620,7 @@ static hipError_t launch_iterate(const MkFusedDesc* d_desc, int nq, double* q, c
                                  double ori_tol, double* v, int32_t* iters, double* err, int32_t* status,
                                  hipStream_t stream) {
   const int blocks = (B + 63) / 64;
-  const size_t lds = (size_t)64 * (nq | 1) * sizeof(double);
+  const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
   hipLaunchKernelGGL(fused_iterate_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
                      target_stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status);
   return hipGetLastError();

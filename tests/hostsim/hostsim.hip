@@ -5,6 +5,7 @@
 // same templates lane by lane on the CPU, so the structured QP build / active-set
 // logic can be checked against the oracle in the CPU test suite (no GPU needed).
 // It is never loaded by the mink_amd package.
+#define MK_QP_STATS 1
 #include "../../mink_amd/csrc/mk_api.hip"
 #include "../../mink_amd/csrc/mk_fused.hip"
 
@@ -14,6 +15,7 @@ template <int NC>
 int run_step(const MkFusedDesc& D, const double* q, const double* targets, int stride, double dt, double damping,
              int B, double* v, int32_t* status) {
   std::vector<double> row(D.nq + 1);
+  double hbuf[MK_MAX_CHAIN * (MK_MAX_CHAIN + 1) / 2];
   for (int b = 0; b < B; ++b) {
     memcpy(row.data(), q + (size_t)b * D.nq, D.nq * sizeof(double));
     const double* tg = targets + (size_t)b * stride + D.target_off;
@@ -21,9 +23,10 @@ int run_step(const MkFusedDesc& D, const double* q, const double* targets, int s
     for (int k = 0; k < NC; ++k) qc[k] = row[D.seg[k].qadr];
     ChainFK<NC> fk;
     chain_fk<NC>(&D, qc, Q4{tg[0], tg[1], tg[2], tg[3]}, v3(tg[4], tg[5], tg[6]), fk);
-    status[b] = solve_problem<NC, false>(&D, row.data(), qc, fk, dt, damping, x, nullptr);
+    uint32_t act = 0u, upper = 0u;
+    status[b] = solve_problem<NC, false>(&D, row.data(), qc, fk, dt, 1.0 / dt, damping, x, nullptr, act, upper, false, hbuf, 1);
     for (int k = 0; k < NC; ++k)
-      if (D.seg[k].dof >= 0) row[D.seg[k].dof] = x[k] / dt;
+      if (D.seg[k].dof >= 0) row[D.seg[k].dof] = x[k] * (1.0 / dt);
     memcpy(v + (size_t)b * D.nv, row.data(), D.nv * sizeof(double));
   }
   return 0;
@@ -34,6 +37,7 @@ int run_iterate(const MkFusedDesc& D, double* q, const double* targets, int stri
                 int max_iters, double pos_tol, double ori_tol, double* v, int32_t* iters_out, double* err,
                 int32_t* status_out) {
   std::vector<double> row(D.nq + 1);
+  double hbuf[MK_MAX_CHAIN * (MK_MAX_CHAIN + 1) / 2];
   for (int b = 0; b < B; ++b) {
     memcpy(row.data(), q + (size_t)b * D.nq, D.nq * sizeof(double));
     const double* tg = targets + (size_t)b * stride + D.target_off;
@@ -44,17 +48,18 @@ int run_iterate(const MkFusedDesc& D, double* q, const double* targets, int stri
     double* vrow = v ? v + (size_t)b * D.nv : nullptr;
     Twist e{};
     int status = 0, iters = 0;
+    uint32_t act = 0u, upper = 0u;
     for (int it = 0; it <= max_iters; ++it) {
       ChainFK<NC> fk;
       chain_fk<NC>(&D, qc, Qt, pt, fk);
       e = fk.e;
       const bool conv = it > 0 && sqrt(dot(e.v, e.v)) <= pos_tol && sqrt(dot(e.w, e.w)) <= ori_tol;
       if (conv || it == max_iters) break;
-      int st = solve_problem<NC, true>(&D, row.data(), qc, fk, dt, damping, x, vrow);
+      int st = solve_problem<NC, true>(&D, row.data(), qc, fk, dt, 1.0 / dt, damping, x, vrow, act, upper, it > 0, hbuf, 1);
       status = std::max(status, st);
       iters = it + 1;
       for (int k = 0; k < NC; ++k) {
-        double vk = x[k] / dt;
+        double vk = x[k] * (1.0 / dt);
         x[k] = vk;
         qc[k] = qc[k] + dt * vk;
         if (D.seg[k].dof >= 0) row[D.seg[k].qadr] = qc[k];
@@ -120,4 +125,11 @@ extern "C" int hostsim_iterate(const mk_model_desc* md, const mk_task_desc* task
   int rc = build(md, tasks, ntask, limits, nlimit, D, &nk, &stride);
   if (rc != MK_OK) return rc;
   HS_DISPATCH(run_iterate, D, q, targets, stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status)
+}
+
+// solves, phase-1 rounds, phase-2 steps, factorizations since the last reset
+extern "C" void hostsim_qp_stats(long* out, int reset) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  for (int i = 0; i < 4; ++i) { out[i] = g_qp_stats[i]; if (reset) g_qp_stats[i] = 0; }
+#endif
 }
