@@ -178,9 +178,15 @@ int mk_build_qp_batch(const mk_problem* problem, const double* d_q, const double
                       double dt, double damping, int32_t B, double* d_P, double* d_c,
                       double* d_G, double* d_h, void* stream);
 
+/* Task.compute_error / Task.compute_jacobian of task number `task` of the problem
+ * (mink/tasks/task.py:81-103 and the subclasses): d_err [B, k], d_jac [B, k, nv] with
+ * k = 6 (frame tasks), nv (posture) or 3 (com); either output may be NULL. */
+int mk_task_eval_batch(const mk_problem* problem, int32_t task, const double* d_q, const double* d_targets,
+                       int32_t B, double* d_err, double* d_jac, void* stream);
+
 /* qpsolvers.solve_problem(Problem(P, q, G, h), solver) (mink/solve_ik.py:101):
  * min 1/2 x'Px + c'x s.t. Gx <= h for B independent dense problems, P positive
- * definite; n <= 64, m <= 256.  d_x [B, n]. */
+ * definite; n <= 64 and (4 n^2 + m n) * 8 bytes within the LDS budget (~150 KB).  d_x [B, n]. */
 int mk_qp_solve_batch(const double* d_P, const double* d_c, const double* d_G, const double* d_h,
                       int32_t n, int32_t m, int32_t B, double* d_x, int32_t* d_status,
                       void* stream);

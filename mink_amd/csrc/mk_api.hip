@@ -111,7 +111,11 @@ struct mk_problem {
   int nc_kernel;            // template size used by the fused kernels
   MkFusedDesc* d_fused;     // device copy
   MkFusedDesc h_fused;
-  MkGenericProblem gen;     // generic (dense) path description, device pointers owned below
+  bool dense;               // the dense (general) path can serve this problem
+  std::string dense_why;    // why not, otherwise
+  MkDenseProblem h_dense;
+  MkDenseProblem* d_dense;
+  std::vector<int> task_k;  // error dimension of each task
   std::vector<void*> allocs;
 };
 
@@ -341,6 +345,106 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
   return true;
 }
 
+// Describes the problem for the dense (wave-per-problem) kernels. Device arrays go to
+// `allocs`. Returns false with `why` when a feature is outside what they implement.
+bool build_dense(const HostModel& m, const mk_task_desc* tasks, int ntask, const mk_limit_desc* limits, int nlimit,
+                 MkDenseProblem& D, std::vector<int>& task_k, std::vector<void*>& allocs, std::string& why) {
+  memset(&D, 0, sizeof(D));
+  if (m.nv > MK_DENSE_MAX_NV) { why = "more than 64 dofs"; return false; }
+  if (ntask > MK_DENSE_MAX_TASKS || nlimit > MK_DENSE_MAX_LIMITS) { why = "too many tasks or limits"; return false; }
+  bool has_ball = false;
+  for (int j = 0; j < m.njnt; ++j) has_ball |= m.jnt_type[j] == MK_JNT_BALL;
+  D.ntask = ntask;
+  D.nlimit = nlimit;
+  int off = 0;
+  for (int t = 0; t < ntask; ++t) {
+    const mk_task_desc& T = tasks[t];
+    MkDenseTask& O = D.task[t];
+    O.type = T.type;
+    O.gain = T.gain;
+    O.lm = T.lm_damping;
+    O.target_off = off;
+    if (T.type == MK_TASK_FRAME || T.type == MK_TASK_RELATIVE_FRAME) {
+      if (T.ncost != 6) { why = "frame task cost must have 6 entries"; return false; }
+      memcpy(O.cost, T.cost, 6 * sizeof(double));
+      if (frame_body_and_local(m, T.frame_type, T.frame_id, &O.body, O.lpos, O.lquat) != MK_OK) { why = g_last_error; return false; }
+      if (T.type == MK_TASK_RELATIVE_FRAME &&
+          frame_body_and_local(m, T.root_type, T.root_id, &O.root_body, O.rpos, O.rquat) != MK_OK) { why = g_last_error; return false; }
+      O.k = 6;
+      off += 7;
+    } else if (T.type == MK_TASK_POSTURE) {
+      if (has_ball) { why = "posture task on a model with ball joints"; return false; }
+      if (T.ncost != m.nv || !T.target_q) { why = "posture task needs nv costs and a target"; return false; }
+      std::vector<double> pc(T.cost, T.cost + m.nv), pt(T.target_q, T.target_q + m.nq);
+      if (upload(allocs, pc, &O.pcost) != MK_OK || upload(allocs, pt, &O.ptarget) != MK_OK) { why = g_last_error; return false; }
+      O.k = m.nv;
+    } else {  // com: subtree of body 1 (mink/tasks/com_task.py:82,96)
+      if (T.ncost != 3) { why = "com task cost must have 3 entries"; return false; }
+      memcpy(O.cost, T.cost, 3 * sizeof(double));
+      std::vector<int32_t> bodies;
+      for (int b = 1; b < m.nbody; ++b) {
+        int x = b;
+        while (x > 1) x = m.body_parentid[x];
+        if (x == 1) bodies.push_back(b);
+      }
+      O.nbodies = (int)bodies.size();
+      if (upload(allocs, bodies, &O.bodies) != MK_OK) { why = g_last_error; return false; }
+      O.k = 3;
+      off += 3;
+    }
+    task_k.push_back(O.k);
+  }
+  D.target_stride = off;
+  int rows = 0;
+  for (int l = 0; l < nlimit; ++l) {
+    const mk_limit_desc& L = limits[l];
+    MkDenseLimit& O = D.limit[l];
+    O.type = L.type;
+    O.row0 = rows;
+    if (L.type == MK_LIMIT_CONFIGURATION) {
+      std::vector<int32_t> idx;
+      for (int j = 0; j < m.njnt; ++j) {
+        if (m.jnt_type[j] == MK_JNT_FREE || !m.jnt_limited[j]) continue;
+        if (m.jnt_type[j] == MK_JNT_BALL) { why = "configuration limit on a ball joint"; return false; }
+        idx.push_back(j);
+      }
+      O.n = (int)idx.size();
+      O.gain = L.gain;
+      O.min_dist = L.min_distance_from_limits;
+      if (upload(allocs, idx, &O.index) != MK_OK) { why = g_last_error; return false; }
+      rows += 2 * O.n;
+    } else if (L.type == MK_LIMIT_VELOCITY) {
+      std::vector<int32_t> idx(L.index, L.index + L.n);
+      std::vector<double> vm(L.vmax, L.vmax + L.n);
+      for (int d : idx)
+        if (d < 0 || d >= m.nv) { why = "velocity limit dof out of range"; return false; }
+      O.n = L.n;
+      if (upload(allocs, idx, &O.index) != MK_OK || upload(allocs, vm, &O.vmax) != MK_OK) { why = g_last_error; return false; }
+      rows += 2 * O.n;
+    } else {
+      std::vector<int32_t> idx(L.index, L.index + 2 * L.n);
+      for (int k = 0; k < L.n; ++k) {
+        const int g1 = idx[2 * k], g2 = idx[2 * k + 1];
+        if (g1 < 0 || g1 >= m.ngeom || g2 < 0 || g2 >= m.ngeom) { why = "geom id out of range"; return false; }
+        int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+        if (t1 > t2) std::swap(t1, t2);
+        const bool ok = (t1 == 0 && (t2 == 6 || t2 == 2)) || (t1 == 2 && t2 == 2) || (t1 == 6 && t2 == 6);
+        if (!ok) { why = "geom pair types without a distance routine (supported: plane-box, plane-sphere, sphere-sphere, box-box)"; return false; }
+      }
+      O.n = L.n;
+      O.gain = L.gain;
+      O.d_min = L.minimum_distance_from_collisions;
+      O.d_detect = L.collision_detection_distance;
+      O.relax = L.bound_relaxation;
+      if (upload(allocs, idx, &O.index) != MK_OK) { why = g_last_error; return false; }
+      rows += O.n;
+    }
+  }
+  D.n_rows = rows;
+  if (mk_dense_lds_bytes(m.nv, rows) == 0) { why = "problem does not fit the LDS budget of the dense kernels"; return false; }
+  return true;
+}
+
 int count_rows(const HostModel& m, const mk_limit_desc* limits, int nlimit) {
   int rows = 0;
   for (int l = 0; l < nlimit; ++l) {
@@ -433,15 +537,26 @@ int mk_model_create(const mk_model_desc* d, mk_model** out) {
     path_len[b] = (int32_t)p.size();
     path_data.insert(path_data.end(), p.begin(), p.end());
   }
+  std::vector<int32_t> dof_qadr(h.nv), dof_scalar(h.nv);
+  for (int j = 0; j < h.njnt; ++j) {
+    const int t = h.jnt_type[j], w = t == MK_JNT_FREE ? 6 : t == MK_JNT_BALL ? 3 : 1;
+    for (int k = 0; k < w; ++k) {
+      dof_qadr[h.jnt_dofadr[j] + k] = h.jnt_qposadr[j] + k;
+      dof_scalar[h.jnt_dofadr[j] + k] = (t == MK_JNT_HINGE || t == MK_JNT_SLIDE) ? 1 : 0;
+    }
+  }
   MkDevModel& dv = m->dev;
   memset(&dv, 0, sizeof(dv));
-  dv.nq = h.nq; dv.nv = h.nv; dv.nbody = h.nbody; dv.njnt = h.njnt;
+  dv.nq = h.nq; dv.nv = h.nv; dv.nbody = h.nbody; dv.njnt = h.njnt; dv.ngeom = h.ngeom;
   int rc = MK_OK;
 #define UP(field) if (rc == MK_OK) rc = upload(m->allocs, h.field, &dv.field)
   UP(body_parentid); UP(body_jntadr); UP(body_jntnum); UP(body_mocapid); UP(body_pos); UP(body_quat);
   UP(jnt_type); UP(jnt_qposadr); UP(jnt_dofadr); UP(jnt_bodyid); UP(jnt_limited); UP(jnt_pos); UP(jnt_axis);
-  UP(jnt_range); UP(qpos0);
+  UP(jnt_range); UP(qpos0); UP(body_mass); UP(body_ipos);
+  UP(geom_bodyid); UP(geom_type); UP(geom_size); UP(geom_pos); UP(geom_quat);
 #undef UP
+  if (rc == MK_OK) rc = upload(m->allocs, dof_qadr, &dv.dof_qadr);
+  if (rc == MK_OK) rc = upload(m->allocs, dof_scalar, &dv.dof_scalar);
   if (rc == MK_OK) rc = upload(m->allocs, path_adr, &dv.path_adr);
   if (rc == MK_OK) rc = upload(m->allocs, path_len, &dv.path_len);
   if (rc == MK_OK) rc = upload(m->allocs, path_data, &dv.path_data);
@@ -488,7 +603,7 @@ int mk_problem_create(const mk_model* model, const mk_task_desc* tasks, int32_t 
   mk_problem* p = new mk_problem();
   p->model = model;
   p->d_fused = nullptr;
-  memset(&p->gen, 0, sizeof(p->gen));
+  p->d_dense = nullptr;
   p->info.nq = m.nq;
   p->info.nv = m.nv;
   p->info.target_stride = stride;
@@ -507,8 +622,23 @@ int mk_problem_create(const mk_model* model, const mk_task_desc* tasks, int32_t 
     }
     p->d_fused = static_cast<MkFusedDesc*>(d);
     p->allocs.push_back(d);
-  } else {
-    g_last_error = "dense path required: " + why;
+  }
+  p->dense = build_dense(m, tasks, ntask, limits, nlimit, p->h_dense, p->task_k, p->allocs, p->dense_why);
+  if (p->dense) {
+    void* d = nullptr;
+    if (hipMalloc(&d, sizeof(MkDenseProblem)) != hipSuccess ||
+        hipMemcpy(d, &p->h_dense, sizeof(MkDenseProblem), hipMemcpyHostToDevice) != hipSuccess) {
+      if (d) (void)hipFree(d);
+      mk_problem_destroy(p);
+      return fail(MK_ERR_HIP, "could not upload the problem descriptor");
+    }
+    p->d_dense = static_cast<MkDenseProblem*>(d);
+    p->allocs.push_back(d);
+  }
+  if (!p->fused && !p->dense) {
+    std::string msg = "no kernel path serves this problem: fused: " + why + "; dense: " + p->dense_why;
+    mk_problem_destroy(p);
+    return fail(MK_ERR_UNSUPPORTED, "%s", msg.c_str());
   }
   *out = p;
   return MK_OK;
@@ -533,7 +663,12 @@ int mk_solve_ik_batch(const mk_problem* p, const double* d_q, const double* d_ta
   if (B == 0) return MK_OK;
   if (!d_q || !d_v || !d_status) return fail(MK_ERR_INVALID, "null argument");
   if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
-  if (!p->fused) return fail(MK_ERR_UNSUPPORTED, "this task/limit set needs the dense path (mk_build_qp_batch + mk_qp_solve_batch)");
+  if (!p->fused) {
+    MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, d_q, d_targets, p->info.target_stride, dt,
+                           damping, B, nullptr, nullptr, nullptr, nullptr, d_v, d_status, -1, nullptr, nullptr,
+                           static_cast<hipStream_t>(stream)));
+    return MK_OK;
+  }
   MK_HIP(mk_fused_launch_step(p->nc_kernel, p->d_fused, p->info.nq, d_q, d_targets, p->info.target_stride, dt,
                               damping, B, d_v, d_status, static_cast<hipStream_t>(stream)));
   return MK_OK;
@@ -598,14 +733,41 @@ int mk_check_limits_batch(const mk_model* m, const double* d_q, double tol, int3
 
 int mk_build_qp_batch(const mk_problem* p, const double* d_q, const double* d_targets, double dt, double damping,
                       int32_t B, double* d_P, double* d_c, double* d_G, double* d_h, void* stream) {
-  (void)p; (void)d_q; (void)d_targets; (void)dt; (void)damping; (void)B; (void)d_P; (void)d_c; (void)d_G; (void)d_h; (void)stream;
-  return fail(MK_ERR_UNSUPPORTED, "mk_build_qp_batch is not implemented yet");
+  if (!p) return fail(MK_ERR_INVALID, "null problem");
+  if (B < 0 || !(dt > 0.0) || !(damping >= 0.0)) return fail(MK_ERR_INVALID, "B, dt or damping out of range");
+  if (B == 0) return MK_OK;
+  if (!d_q || !d_P || !d_c) return fail(MK_ERR_INVALID, "null argument");
+  if (p->info.n_rows > 0 && (!d_G || !d_h)) return fail(MK_ERR_INVALID, "G and h are required when the problem has limits");
+  if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
+  if (!p->dense) return fail(MK_ERR_UNSUPPORTED, "dense path unavailable: %s", p->dense_why.c_str());
+  MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, d_q, d_targets, p->info.target_stride, dt, damping,
+                         B, d_P, d_c, p->info.n_rows > 0 ? d_G : nullptr, d_h, nullptr, nullptr, -1, nullptr, nullptr,
+                         static_cast<hipStream_t>(stream)));
+  return MK_OK;
+}
+
+int mk_task_eval_batch(const mk_problem* p, int32_t task, const double* d_q, const double* d_targets, int32_t B,
+                       double* d_err, double* d_jac, void* stream) {
+  if (!p) return fail(MK_ERR_INVALID, "null problem");
+  if (B < 0 || task < 0 || task >= p->h_dense.ntask) return fail(MK_ERR_INVALID, "batch or task index out of range");
+  if (B == 0) return MK_OK;
+  if (!d_q || (!d_err && !d_jac)) return fail(MK_ERR_INVALID, "null argument");
+  if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
+  if (!p->dense) return fail(MK_ERR_UNSUPPORTED, "dense path unavailable: %s", p->dense_why.c_str());
+  MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, d_q, d_targets, p->info.target_stride, 1.0, 0.0, B,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, task, d_err, d_jac,
+                         static_cast<hipStream_t>(stream)));
+  return MK_OK;
 }
 
 int mk_qp_solve_batch(const double* d_P, const double* d_c, const double* d_G, const double* d_h, int32_t n, int32_t m,
                       int32_t B, double* d_x, int32_t* d_status, void* stream) {
-  (void)d_P; (void)d_c; (void)d_G; (void)d_h; (void)n; (void)m; (void)B; (void)d_x; (void)d_status; (void)stream;
-  return fail(MK_ERR_UNSUPPORTED, "mk_qp_solve_batch is not implemented yet");
+  if (n <= 0 || m < 0 || B < 0) return fail(MK_ERR_INVALID, "n, m or B out of range");
+  if (B == 0) return MK_OK;
+  if (!d_P || !d_c || !d_x || !d_status || (m > 0 && (!d_G || !d_h))) return fail(MK_ERR_INVALID, "null argument");
+  if (mk_dense_lds_bytes(n, m) == 0) return fail(MK_ERR_UNSUPPORTED, "QP too large for the LDS-resident solver (n <= 64 and (4 n^2 + m n) * 8 bytes <= ~150 KB)");
+  MK_HIP(mk_dense_qp_launch(d_P, d_c, d_G, d_h, n, m, B, d_x, d_status, static_cast<hipStream_t>(stream)));
+  return MK_OK;
 }
 
 }  // extern "C"

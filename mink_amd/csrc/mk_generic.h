@@ -1,22 +1,57 @@
-// Generic (any tree, any frame) utility kernels: integrate, frame pose / Jacobian,
-// limit check.  One problem per thread; the model tables are read through uniform
-// (scalar) loads.
+// Device-side model tables and the launchers of the generic (any tree, any task /
+// limit set) kernels: utility kernels in mk_generic.hip, the dense QP build + solve in
+// mk_dense.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 struct MkDevModel {
-  int32_t nq, nv, nbody, njnt;
+  int32_t nq, nv, nbody, njnt, ngeom;
   const int32_t *body_parentid, *body_jntadr, *body_jntnum, *body_mocapid;
-  const double *body_pos, *body_quat;
+  const double *body_pos, *body_quat, *body_mass, *body_ipos;
   const int32_t *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
   const double *jnt_pos, *jnt_axis, *jnt_range, *qpos0;
+  const int32_t *dof_qadr, *dof_scalar;   // per dof: qpos address, 1 for hinge / slide dofs
+  const int32_t *geom_bodyid, *geom_type;
+  const double *geom_size, *geom_pos, *geom_quat;
   const int32_t *path_adr, *path_len, *path_data;  // bodies from the root to each body
 };
 
-// Placeholder for the dense-path problem description (device pointers).
-struct MkGenericProblem {
-  int32_t ntask, nlimit;
+constexpr int MK_DENSE_MAX_TASKS = 8;
+constexpr int MK_DENSE_MAX_LIMITS = 8;
+constexpr int MK_DENSE_MAX_NV = 64;
+
+// One task of the dense path; frames are resolved to (body, local offset).
+struct MkDenseTask {
+  int32_t type;            // MK_TASK_*
+  int32_t body, root_body;
+  int32_t target_off;      // offset of this task's per-problem target
+  double lpos[3], lquat[4];
+  double rpos[3], rquat[4];
+  double cost[6];          // frame tasks / com (first 3)
+  double gain, lm;
+  const double* pcost;     // posture: [nv] device
+  const double* ptarget;   // posture: [nq] device
+  const int32_t* bodies;   // com: bodies of the subtree (device)
+  int32_t nbodies;
+  int32_t k;               // error dimension: 6, nv or 3
+};
+
+struct MkDenseLimit {
+  int32_t type;            // MK_LIMIT_*
+  int32_t n;               // velocity: dofs; collision: pairs; configuration: limited joints
+  int32_t row0;            // first row in G
+  int32_t pad;
+  double gain, min_dist;   // configuration
+  const int32_t* index;    // configuration: joint ids; velocity: dof ids; collision: 2n geom ids
+  const double* vmax;
+  double d_min, d_detect, relax;
+};
+
+struct MkDenseProblem {
+  int32_t ntask, nlimit, n_rows, target_stride;
+  MkDenseTask task[MK_DENSE_MAX_TASKS];
+  MkDenseLimit limit[MK_DENSE_MAX_LIMITS];
 };
 
 hipError_t mk_generic_integrate(const MkDevModel& m, double* q, const double* v, double dt, int B, hipStream_t s);
@@ -26,3 +61,15 @@ hipError_t mk_generic_frame(const MkDevModel& m, const double* q, int B, int bod
                             const double* lquat, double* d_pose, double* d_jac, hipStream_t s);
 hipError_t mk_generic_check_limits(const MkDevModel& m, const double* q, double tol, int B, int32_t* first,
                                    hipStream_t s);
+
+// Dense path (mk_dense.hip).  Bytes of LDS one problem needs, or 0 if it cannot run.
+size_t mk_dense_lds_bytes(int nv, int n_rows);
+// Builds the QP of every problem and, depending on the outputs given, writes it out
+// (P/c/G/h), solves it (v/status) and/or reports one task's error and Jacobian.
+hipError_t mk_dense_launch(const MkDevModel& m, const MkDenseProblem* d_problem, int n_rows, const double* q,
+                           const double* targets, int target_stride, double dt, double damping, int B, double* P,
+                           double* c, double* G, double* h, double* v, int32_t* status, int eval_task, double* err,
+                           double* jac, hipStream_t s);
+// Solves caller-provided dense QPs.
+hipError_t mk_dense_qp_launch(const double* P, const double* c, const double* G, const double* h, int n, int m, int B,
+                              double* x, int32_t* status, hipStream_t s);

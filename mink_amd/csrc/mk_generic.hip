@@ -6,6 +6,7 @@
 
 #include "../../include/mink_amd.h"
 #include "mk_device.h"
+#include "mk_tree.h"
 
 namespace {
 
@@ -42,83 +43,20 @@ __global__ void integrate_kernel(MkDevModel m, double* __restrict__ q, const dou
   qq[0] = r.w; qq[1] = r.x; qq[2] = r.y; qq[3] = r.z;
 }
 
-struct BodyState {
-  V3 p;
-  Q4 Q;
-  M3 R;
-};
-
-// Advances (p, Q, R) from the parent frame through body `b`; when JAC, also emits the
-// body-frame Jacobian columns of this body's dofs for a frame at (ps, Rs).
-template <bool JAC>
-MK_DEV void advance_body(const MkDevModel& m, const double* __restrict__ q, int b, BodyState& st, V3 ps, const M3& Rs,
-                         double* __restrict__ jac) {
-  const int ja = m.body_jntadr[b], jn = m.body_jntnum[b];
-  const int nv = m.nv;
-  auto emit = [&](int dof, V3 lin, V3 ang) {
+// Emits body-frame Jacobian columns (rows linear; angular) of the frame at (ps, Rs).
+struct FrameJacEmit {
+  V3 ps;
+  M3 Rs;
+  double* jac;
+  int nv;
+  MK_DEV void operator()(int dof, int kind, V3 axis, V3 anchor) {
+    V3 lin = kind == MK_COL_ROT ? cross(axis, ps - anchor) : axis;
+    V3 ang = kind == MK_COL_ROT ? axis : v3(0, 0, 0);
     V3 bl = mulT(Rs, lin), ba = mulT(Rs, ang);
     jac[0 * nv + dof] = bl.x; jac[1 * nv + dof] = bl.y; jac[2 * nv + dof] = bl.z;
     jac[3 * nv + dof] = ba.x; jac[4 * nv + dof] = ba.y; jac[5 * nv + dof] = ba.z;
-  };
-  if (jn == 1 && m.jnt_type[ja] == MK_JNT_FREE) {
-    const double* qq = q + m.jnt_qposadr[ja];
-    st.p = v3(qq[0], qq[1], qq[2]);
-    st.Q = qnormalize(Q4{qq[3], qq[4], qq[5], qq[6]});
-    st.R = q2m(st.Q);
-    if (JAC) {
-      const int d0 = m.jnt_dofadr[ja];
-      emit(d0 + 0, v3(1, 0, 0), v3(0, 0, 0));
-      emit(d0 + 1, v3(0, 1, 0), v3(0, 0, 0));
-      emit(d0 + 2, v3(0, 0, 1), v3(0, 0, 0));
-      for (int k = 0; k < 3; ++k) {
-        V3 ax = v3(st.R.m[k], st.R.m[3 + k], st.R.m[6 + k]);
-        emit(d0 + 3 + k, cross(ax, ps - st.p), ax);
-      }
-    }
-    return;
   }
-  st.p = st.p + mul(st.R, v3(m.body_pos[3 * b], m.body_pos[3 * b + 1], m.body_pos[3 * b + 2]));
-  st.Q = qmul(st.Q, Q4{m.body_quat[4 * b], m.body_quat[4 * b + 1], m.body_quat[4 * b + 2], m.body_quat[4 * b + 3]});
-  st.R = q2m(st.Q);
-  // ball-joint columns need the body's final orientation: remember them
-  int ball_dof = -1;
-  V3 ball_anchor = v3(0, 0, 0);
-  for (int j = ja; j < ja + jn; ++j) {
-    const int t = m.jnt_type[j];
-    const int qa = m.jnt_qposadr[j], d0 = m.jnt_dofadr[j];
-    V3 jpos = v3(m.jnt_pos[3 * j], m.jnt_pos[3 * j + 1], m.jnt_pos[3 * j + 2]);
-    V3 axl = v3(m.jnt_axis[3 * j], m.jnt_axis[3 * j + 1], m.jnt_axis[3 * j + 2]);
-    V3 ax = mul(st.R, axl);
-    V3 an = st.p + mul(st.R, jpos);
-    if (t == MK_JNT_SLIDE) {
-      st.p = st.p + (q[qa] - m.qpos0[qa]) * ax;
-      if (JAC) emit(d0, ax, v3(0, 0, 0));
-    } else {
-      Q4 ql;
-      if (t == MK_JNT_BALL) {
-        ql = qnormalize(Q4{q[qa], q[qa + 1], q[qa + 2], q[qa + 3]});
-        ball_dof = d0;
-        ball_anchor = an;
-      } else {
-        double sn, cs;
-        sincos(0.5 * (q[qa] - m.qpos0[qa]), &sn, &cs);
-        ql = Q4{cs, sn * axl.x, sn * axl.y, sn * axl.z};
-        if (JAC) emit(d0, cross(ax, ps - an), ax);
-      }
-      st.Q = qmul(st.Q, ql);
-      st.R = q2m(st.Q);
-      st.p = an - mul(st.R, jpos);
-    }
-  }
-  st.Q = qnormalize(st.Q);
-  st.R = q2m(st.Q);
-  if (JAC && ball_dof >= 0) {
-    for (int k = 0; k < 3; ++k) {
-      V3 ax = v3(st.R.m[k], st.R.m[3 + k], st.R.m[6 + k]);
-      emit(ball_dof + k, cross(ax, ps - ball_anchor), ax);
-    }
-  }
-}
+};
 
 __global__ void frame_kernel(MkDevModel m, const double* __restrict__ q, int B, int body, V3 lpos, Q4 lquat,
                              double* __restrict__ pose, double* __restrict__ jac) {
@@ -126,9 +64,9 @@ __global__ void frame_kernel(MkDevModel m, const double* __restrict__ q, int B, 
   if (b >= B) return;
   const double* qb = q + b * m.nq;
   const int adr = m.path_adr[body], len = m.path_len[body];
-  BodyState st{v3(0, 0, 0), Q4{1, 0, 0, 0}, M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}}};
-  M3 none{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
-  for (int i = 0; i < len; ++i) advance_body<false>(m, qb, m.path_data[adr + i], st, v3(0, 0, 0), none, nullptr);
+  BodyState st = body_state_identity();
+  NoEmit none;
+  for (int i = 0; i < len; ++i) advance_body<false>(m, qb, m.path_data[adr + i], st, none);
   V3 ps = st.p + mul(st.R, lpos);
   Q4 Qs = qmul(st.Q, lquat);
   if (pose) {
@@ -138,9 +76,9 @@ __global__ void frame_kernel(MkDevModel m, const double* __restrict__ q, int B, 
   if (jac) {
     double* jb = jac + b * 6 * m.nv;
     for (int i = 0; i < 6 * m.nv; ++i) jb[i] = 0.0;
-    M3 Rs = q2m(Qs);
-    BodyState s2{v3(0, 0, 0), Q4{1, 0, 0, 0}, M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}}};
-    for (int i = 0; i < len; ++i) advance_body<true>(m, qb, m.path_data[adr + i], s2, ps, Rs, jb);
+    FrameJacEmit em{ps, q2m(Qs), jb, m.nv};
+    BodyState s2 = body_state_identity();
+    for (int i = 0; i < len; ++i) advance_body<true>(m, qb, m.path_data[adr + i], s2, em);
   }
 }
 

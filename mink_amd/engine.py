@@ -133,6 +133,33 @@ class DeviceProblem:
                                                _stream_ptr(self.device)))
         return v, status
 
+    def build_qp(self, q: torch.Tensor, targets: Optional[torch.Tensor], dt: float, damping: float):
+        """Dense (P, c, G, h) of every problem; G, h are None without limit rows."""
+        B = q.shape[0]
+        _check_tensor(q, (B, self.nq), torch.float64, "q")
+        n, m = self.nv, self.n_rows
+        P = torch.empty((B, n, n), dtype=torch.float64, device=self.device)
+        c = torch.empty((B, n), dtype=torch.float64, device=self.device)
+        G = torch.empty((B, m, n), dtype=torch.float64, device=self.device) if m else None
+        h = torch.empty((B, m), dtype=torch.float64, device=self.device) if m else None
+        with torch.cuda.device(self.device):
+            L.check(self.lib.mk_build_qp_batch(self.handle, q.data_ptr(), self._targets_ptr(targets, B), float(dt),
+                                               float(damping), B, P.data_ptr(), c.data_ptr(),
+                                               G.data_ptr() if m else None, h.data_ptr() if m else None,
+                                               _stream_ptr(self.device)))
+        return P, c, G, h
+
+    def task_eval(self, task: int, k: int, q: torch.Tensor, targets: Optional[torch.Tensor]):
+        """(error [B, k], Jacobian [B, k, nv]) of task number `task`."""
+        B = q.shape[0]
+        _check_tensor(q, (B, self.nq), torch.float64, "q")
+        err = torch.empty((B, k), dtype=torch.float64, device=self.device)
+        jac = torch.empty((B, k, self.nv), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.mk_task_eval_batch(self.handle, int(task), q.data_ptr(), self._targets_ptr(targets, B),
+                                                B, err.data_ptr(), jac.data_ptr(), _stream_ptr(self.device)))
+        return err, jac
+
     def iterate_(self, q: torch.Tensor, targets: Optional[torch.Tensor], dt: float, damping: float, max_iters: int,
                  pos_tol: float = -1.0, ori_tol: float = -1.0, want_v: bool = False, out: Optional[dict] = None):
         """In-place loop on q. Returns dict(iters, err, status[, v])."""
@@ -161,3 +188,22 @@ class DeviceProblem:
         if v is not None:
             res["v"] = v
         return res
+
+
+def qp_solve(P: torch.Tensor, c: torch.Tensor, G: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None):
+    """Batched dense QP: min 1/2 x'Px + c'x s.t. Gx <= h. Returns (x [B, n], status [B])."""
+    lib = L.load_library()
+    B, n = c.shape
+    _check_tensor(P, (B, n, n), torch.float64, "P")
+    _check_tensor(c, (B, n), torch.float64, "c")
+    m = 0 if G is None else G.shape[1]
+    if m:
+        _check_tensor(G, (B, m, n), torch.float64, "G")
+        _check_tensor(h, (B, m), torch.float64, "h")
+    x = torch.empty((B, n), dtype=torch.float64, device=P.device)
+    status = torch.empty((B,), dtype=torch.int32, device=P.device)
+    with torch.cuda.device(P.device):
+        L.check(lib.mk_qp_solve_batch(P.data_ptr(), c.data_ptr(), G.data_ptr() if m else None,
+                                      h.data_ptr() if m else None, n, m, B, x.data_ptr(), status.data_ptr(),
+                                      _stream_ptr(P.device)))
+    return x, status

@@ -331,66 +331,112 @@ def _box_support_points(center, rot, half):
     return center + (signs * half) @ rot.T
 
 
-def _closest_box_box(c1, r1, h1, c2, r2, h2):
-    """Closest points between two separated oriented boxes, by GJK on the
-    Minkowski difference with an exact closest-point-on-simplex sub-solver.
-    Returns (dist, p1, p2); dist <= 0 reports overlap with p1 = p2 = midpoint."""
+def _point_box(p, c, r, h):
+    """Closest point on the box (centre c, axes r, half sizes h) to p."""
+    loc = r.T @ (p - c)
+    return c + r @ np.clip(loc, -h, h)
 
-    def support(d):
-        s1 = c1 + r1 @ (np.sign(r1.T @ d + 1e-300) * h1)
-        s2 = c2 + r2 @ (np.sign(r2.T @ (-d) + 1e-300) * h2)
-        return s1 - s2, s1, s2
 
-    def closest_on_simplex(W):
-        # Enumerate sub-simplices (<= 4 points): exact for these tiny sets.
-        best = None
-        n = len(W)
-        import itertools
-        for k in range(1, n + 1):
-            for idx in itertools.combinations(range(n), k):
-                P = np.array([W[i] for i in idx])
-                if k == 1:
-                    lam = np.array([1.0])
-                else:
-                    A = (P[1:] - P[0]).T
-                    try:
-                        t = np.linalg.solve(A.T @ A, -A.T @ P[0])
-                    except np.linalg.LinAlgError:
-                        continue
-                    lam = np.concatenate([[1.0 - t.sum()], t])
-                if np.any(lam < -1e-14):
-                    continue
-                v = lam @ P
-                dd = float(v @ v)
-                if best is None or dd < best[0] - 1e-30:
-                    best = (dd, idx, lam)
-        return best
-
-    d = c1 - c2
-    if float(d @ d) < 1e-30:
-        d = np.array([1.0, 0.0, 0.0])
-    w, a, b = support(-d)
-    W, A, B = [w], [a], [b]
-    v = w
-    for _ in range(64):
-        vv = float(v @ v)
-        if vv < 1e-24:
-            mid = 0.5 * (sum(A) / len(A) + sum(B) / len(B))
-            return 0.0, mid, mid
-        w, a, b = support(-v)
-        if vv - float(v @ w) <= 1e-14 * vv:
-            break
-        W.append(w); A.append(a); B.append(b)
-        dd, idx, lam = closest_on_simplex(W)
-        W = [W[i] for i in idx]; A = [A[i] for i in idx]; B = [B[i] for i in idx]
-        v = lam @ np.array(W)
-        lam_keep = lam
+def _seg_seg(p1, q1, p2, q2):
+    """Closest points of segments [p1, q1] and [p2, q2] (clamped parametric solution)."""
+    d1, d2, r = q1 - p1, q2 - p2, p1 - p2
+    a, e, f = float(d1 @ d1), float(d2 @ d2), float(d2 @ r)
+    eps = 1e-30
+    if a <= eps and e <= eps:
+        s = t = 0.0
+    elif a <= eps:
+        s, t = 0.0, min(max(f / e, 0.0), 1.0)
     else:
-        pass
-    dd, idx, lam = closest_on_simplex(W)
-    p1 = lam @ np.array([A[i] for i in idx])
-    p2 = lam @ np.array([B[i] for i in idx])
-    return math.sqrt(dd), p1, p2
+        c = float(d1 @ r)
+        if e <= eps:
+            t, s = 0.0, min(max(-c / a, 0.0), 1.0)
+        else:
+            b = float(d1 @ d2)
+            den = a * e - b * b
+            s = min(max((b * f - c * e) / den, 0.0), 1.0) if den > eps else 0.0
+            t = (b * s + f) / e
+            if t < 0.0:
+                t, s = 0.0, min(max(-c / a, 0.0), 1.0)
+            elif t > 1.0:
+                t, s = 1.0, min(max((b - c) / a, 0.0), 1.0)
+    return p1 + s * d1, p2 + t * d2
+
+
+def _box_vertices(c, r, h):
+    return [c + r @ (np.array([sx, sy, sz]) * h) for sx in (-1.0, 1.0) for sy in (-1.0, 1.0) for sz in (-1.0, 1.0)]
+
+
+def _box_edges(c, r, h):
+    edges = []
+    for a in range(3):
+        b, cc = (a + 1) % 3, (a + 2) % 3
+        for sb in (-1.0, 1.0):
+            for sc in (-1.0, 1.0):
+                off = np.zeros(3)
+                off[b], off[cc] = sb * h[b], sc * h[cc]
+                lo, hi = off.copy(), off.copy()
+                lo[a], hi[a] = -h[a], h[a]
+                edges.append((c + r @ lo, c + r @ hi))
+    return edges
+
+
+def _closest_box_box(c1, r1, h1, c2, r2, h2):
+    """Signed distance and witness points of two oriented boxes.
+
+    Overlapping boxes (no separating axis among the 15 candidates): dist = -(smallest
+    overlap), along that axis n (pointing from box 1 to box 2), with the witness points
+    pos -/+ dist/2 * n around the midpoint of the two support points.  Separated boxes:
+    exact Euclidean closest points, by enumeration of vertex-box and edge-edge pairs
+    in a fixed order (first strict minimum wins)."""
+    d = c2 - c1
+    axes = [r1[:, i] for i in range(3)] + [r2[:, i] for i in range(3)]
+    for i in range(3):
+        for j in range(3):
+            axes.append(np.cross(r1[:, i], r2[:, j]))
+    best_overlap, best_axis = np.inf, None
+    separated = False
+    for ax in axes:
+        n2 = float(ax @ ax)
+        if n2 < 1e-12:
+            continue
+        ax = ax / math.sqrt(n2)
+        ra = float(np.abs(r1.T @ ax) @ h1)
+        rb = float(np.abs(r2.T @ ax) @ h2)
+        overlap = ra + rb - abs(float(d @ ax))
+        if overlap < 0.0:
+            separated = True
+            break
+        if overlap < best_overlap:
+            best_overlap, best_axis = overlap, (ax if float(d @ ax) >= 0.0 else -ax)
+    if not separated:
+        n = best_axis
+        # support features along n: a component of n that vanishes in a box frame selects
+        # the middle of that extent (face / edge centre), not an arbitrary vertex
+        a1, a2 = r1.T @ n, r2.T @ n
+        s1 = c1 + r1 @ (np.where(np.abs(a1) < 1e-9, 0.0, np.sign(a1)) * h1)
+        s2 = c2 + r2 @ (np.where(np.abs(a2) < 1e-9, 0.0, -np.sign(a2)) * h2)
+        pos = 0.5 * (s1 + s2)
+        dist = -best_overlap
+        return dist, pos - 0.5 * dist * n, pos + 0.5 * dist * n
+    best, p1, p2 = np.inf, None, None
+    for v in _box_vertices(c1, r1, h1):
+        w = _point_box(v, c2, r2, h2)
+        dd = float((v - w) @ (v - w))
+        if dd < best:
+            best, p1, p2 = dd, v, w
+    for v in _box_vertices(c2, r2, h2):
+        w = _point_box(v, c1, r1, h1)
+        dd = float((v - w) @ (v - w))
+        if dd < best:
+            best, p1, p2 = dd, w, v
+    e2 = _box_edges(c2, r2, h2)
+    for (a0, a1) in _box_edges(c1, r1, h1):
+        for (b0, b1) in e2:
+            u, w = _seg_seg(a0, a1, b0, b1)
+            dd = float((u - w) @ (u - w))
+            if dd < best:
+                best, p1, p2 = dd, u, w
+    return math.sqrt(best), p1, p2
 
 
 def mj_geomDistance(m, d, g1, g2, distmax):

@@ -1,0 +1,175 @@
+"""GPU parity of the dense (general) path: mk_build_qp_batch / mk_task_eval_batch /
+mk_qp_solve_batch / mk_solve_ik_batch on task and limit sets the fused kernels do not
+serve, against the golden vectors of the reference and the numpy oracle."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from mink_amd import _lib as L
+from mink_amd import workloads as W
+from mink_amd.mjcf import load_builtin
+
+pytestmark = pytest.mark.gpu
+PADS = ["right_pad1", "right_pad2", "left_pad1", "left_pad2"]
+
+
+def dev(a, dtype=torch.float64):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda:0")
+
+
+@pytest.fixture(scope="module")
+def env():
+    from mink_amd.engine import DeviceModel
+    model = load_builtin("tidybot_cube")
+    return model, DeviceModel(model, "cuda:0")
+
+
+def collision_spec(model):
+    from oracle import ik_oracle as o
+    lim = o.CollisionAvoidanceLimit(model, [(PADS, ["cube_geom", "floor"])])
+    return dict(type=L.LIMIT_COLLISION, index=np.array(lim.geom_id_pairs).reshape(-1), gain=0.85,
+                minimum_distance_from_collisions=0.005, collision_detection_distance=0.01,
+                bound_relaxation=0.0), lim
+
+
+def test_build_ik_matches_reference_golden(env, golden_dir):
+    """mink.build_ik: P, q, G, h of the config-2 problem, entry by entry."""
+    from mink_amd.engine import DeviceProblem
+    model, dm = env
+    g = np.load(os.path.join(golden_dir, "tidybot_build_ik.npz"))
+    prob = DeviceProblem(dm, W.task_specs(model, True), W.limit_specs(model, True))
+    P, c, G, h = prob.build_qp(dev(g["q"]), dev(g["target"]), float(g["dt"]), 1e-3)
+    np.testing.assert_allclose(P.cpu().numpy(), g["P"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(c.cpu().numpy(), g["c"], rtol=0, atol=1e-10)
+    np.testing.assert_array_equal(G.cpu().numpy(), g["G"])
+    np.testing.assert_allclose(h.cpu().numpy(), g["h"], rtol=0, atol=1e-13)
+    # per-task error / Jacobian (FrameTask.compute_error / compute_jacobian)
+    err, jac = prob.task_eval(0, 6, dev(g["q"]), dev(g["target"]))
+    np.testing.assert_allclose(err.cpu().numpy(), g["frame_err"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(jac.cpu().numpy(), g["frame_task_jac"], rtol=0, atol=1e-10)
+    err, jac = prob.task_eval(1, model.nv, dev(g["q"]), dev(g["target"]))
+    ref = g["home"][None, :24] - g["q"][:, :24]
+    ref[:, 18:] = 0.0
+    np.testing.assert_allclose(err.cpu().numpy(), ref, rtol=0, atol=1e-14)
+
+
+def test_dense_qp_solver_on_golden_problems(env, golden_dir):
+    """qpsolvers.solve_problem: the stacked golden QPs, solved by the wave-level
+    Goldfarb-Idnani kernel, must give the reference's dq."""
+    from mink_amd.engine import qp_solve
+    g = np.load(os.path.join(golden_dir, "tidybot_build_ik.npz"))
+    x, st = qp_solve(dev(g["P"]), dev(g["c"]), dev(g["G"]), dev(g["h"]))
+    assert int(st.abs().sum()) == 0
+    np.testing.assert_allclose(x.cpu().numpy() / float(g["dt"]), g["v"], rtol=0, atol=1e-9)
+    x, st = qp_solve(dev(g["P"]), dev(g["c"]))
+    assert int(st.abs().sum()) == 0
+    ref = -np.linalg.solve(g["P"], g["c"][..., None])[..., 0]
+    np.testing.assert_allclose(x.cpu().numpy(), ref, rtol=0, atol=1e-10)
+
+
+def test_dense_qp_random_general_rows(env):
+    """Random strictly convex QPs with dense inequality rows, KKT-checked and compared
+    with the oracle's solver (active sets of several general constraints)."""
+    from mink_amd.engine import qp_solve
+    from oracle import ik_oracle as o
+    rng = np.random.default_rng(12)
+    B, n, m = 64, 12, 20
+    A = rng.normal(size=(B, n, n))
+    P = A @ A.transpose(0, 2, 1) + 0.1 * np.eye(n)
+    c = rng.normal(size=(B, n)) * 3
+    G = rng.normal(size=(B, m, n))
+    h = rng.uniform(0.05, 1.0, size=(B, m))
+    x, st = qp_solve(dev(P), dev(c), dev(G), dev(h))
+    x = x.cpu().numpy()
+    assert int(st.abs().sum()) == 0
+    nact = 0
+    for b in range(B):
+        xr, s, act, _ = o.solve_qp(P[b], c[b], G[b], h[b])
+        assert s == 0
+        nact += len(act)
+        np.testing.assert_allclose(x[b], xr, rtol=0, atol=1e-9)
+        assert (G[b] @ x[b] - h[b]).max() < 1e-9
+    assert nact > 2 * B
+    # infeasible: x_0 <= -1 and -x_0 <= -1
+    Gi = np.zeros((1, 2, n)); Gi[0, 0, 0] = 1; Gi[0, 1, 0] = -1
+    x, st = qp_solve(dev(P[:1]), dev(c[:1]), dev(Gi), dev(np.array([[-1.0, -1.0]])))
+    assert st.cpu().tolist() == [2]
+
+
+def test_relative_frame_com_and_collision(env, golden_dir):
+    from mink_amd.engine import DeviceProblem
+    from oracle import ik_oracle as o
+    model, dm = env
+    g = np.load(os.path.join(golden_dir, "tidybot_build_ik.npz"))
+    dt = float(g["dt"])
+    q, B = g["q"], len(g["q"])
+    # RelativeFrameTask + PostureTask with Configuration + Velocity limits (golden v_rel)
+    rel = dict(type=L.TASK_RELATIVE_FRAME, frame_type=2, frame_id=0, root_type=0, root_id=model.body_id("base_link"),
+               cost=[1.0, 2.0, 0.5, 0.7, 0.7, 0.7], gain=0.8, lm_damping=0.5)
+    prob = DeviceProblem(dm, [rel, W.task_specs(model, False)[1]], W.limit_specs(model, True))
+    assert not prob.fused
+    err, jac = prob.task_eval(0, 6, dev(q), dev(g["rel_target"]))
+    np.testing.assert_allclose(err.cpu().numpy(), g["rel_err"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(jac.cpu().numpy(), g["rel_jac"], rtol=0, atol=1e-10)
+    v, st = prob.solve(dev(q), dev(g["rel_target"]), dt, 1e-3)
+    assert int(st.abs().sum()) == 0
+    np.testing.assert_allclose(v.cpu().numpy(), g["v_rel"], rtol=0, atol=1e-9)
+    # ComTask Jacobian / error
+    com = dict(type=L.TASK_COM, cost=[1.0, 1.0, 0.5], gain=1.0, lm_damping=0.0)
+    probc = DeviceProblem(dm, [com], [])
+    tgt = np.zeros((B, 3))
+    err, jac = probc.task_eval(0, 3, dev(q), dev(tgt))
+    np.testing.assert_allclose(jac.cpu().numpy(), g["com_jac"], rtol=0, atol=1e-12)
+    for b in range(0, B, 5):
+        cfg = o.Configuration(model, q[b])
+        np.testing.assert_allclose(err[b].cpu().numpy(), cfg.data.subtree_com[1], rtol=0, atol=1e-13)
+
+
+def test_collision_rows_and_config4_solve(env, golden_dir):
+    from mink_amd.engine import DeviceProblem
+    from oracle import ik_oracle as o
+    model, dm = env
+    g = np.load(os.path.join(golden_dir, "collision.npz"))
+    spec, lim = collision_spec(model)
+    assert [tuple(p) for p in g["pairs"]] == lim.geom_id_pairs
+    prob = DeviceProblem(dm, [], [spec])
+    P, c, G, h = prob.build_qp(dev(g["q"]), None, float(g["dt"]), 1e-3)
+    np.testing.assert_allclose(G.cpu().numpy(), g["G"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(h.cpu().numpy(), g["h"], rtol=1e-9, atol=1e-9)
+    assert np.isfinite(g["h"]).sum() > 5
+    # config-4 style solve: Frame + RelativeFrame + Posture, Cfg + Vel + Collision limits
+    rng = np.random.default_rng(3)
+    B = 96
+    q = W.sample_q(model, rng, B)
+    qs = W.sample_q(model, rng, B)
+    rel = dict(type=L.TASK_RELATIVE_FRAME, frame_type=2, frame_id=0, root_type=0, root_id=1,
+               cost=np.ones(6), gain=1.0, lm_damping=0.0)
+    tasks = [W.task_specs(model, False)[0], rel, W.task_specs(model, False)[1]]
+    prob4 = DeviceProblem(dm, tasks, W.limit_specs(model, True) + [spec])
+    assert prob4.n_rows == 22 + 20 + 8 and prob4.target_stride == 14
+    targets = np.zeros((B, 14))
+    ref_v = []
+    for b in range(B):
+        cfg = o.Configuration(model, q[b])
+        if b % 2 == 0:   # cube close to a pad: active collision rows
+            gid = model.geom_id(PADS[(b // 2) % 4])
+            p = cfg.data.geom_xpos[gid] + rng.normal(size=3) * 0.004
+            d = rng.normal(size=3)
+            q[b, 18:21] = p + d / np.linalg.norm(d) * 0.037
+            qq = rng.normal(size=4)
+            q[b, 21:25] = qq / np.linalg.norm(qq)
+            cfg.update(q[b])
+        tcfg = o.Configuration(model, qs[b])
+        targets[b, :7] = tcfg.get_transform_frame_to_world("pinch_site", "site")
+        targets[b, 7:] = tcfg.get_transform("pinch_site", "site", "base_link", "body")
+        otasks = [o.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0, target=targets[b, :7]),
+                  o.RelativeFrameTask("pinch_site", "site", "base_link", "body", 1.0, 1.0, target=targets[b, 7:]),
+                  o.PostureTask(cost=W.posture_cost(model), target_q=W.home_q(model))]
+        olimits = [o.ConfigurationLimit(model), o.VelocityLimit(model, W.VELOCITY_LIMITS), lim]
+        ref_v.append(o.solve_ik(cfg, otasks, W.DT, damping=W.DAMPING, limits=olimits))
+    v, st = prob4.solve(dev(q), dev(targets), W.DT, W.DAMPING)
+    assert int(st.abs().sum()) == 0
+    np.testing.assert_allclose(v.cpu().numpy(), np.array(ref_v), rtol=0, atol=1e-8)
