@@ -1,0 +1,160 @@
+"""Batched ``Configuration`` (reference: mink/configuration.py:21-253).
+
+Holds B configurations of one kinematic tree on the GPU.  Constructed from a 1-D ``q``
+it behaves like the reference object (numpy in, numpy out, no batch axis); constructed
+from a ``[B, nq]`` array or tensor every quantity gains a leading batch axis and stays
+in device memory.  Kinematics (frame poses, Jacobians, integration, limit check) run in
+the HIP kernels through the C ABI; there is no host fallback.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import constants as consts
+from . import exceptions
+from .engine import DeviceModel
+from .lie import SE3, SO3
+from .mjcf import JNT_FREE, Model
+
+_DEVICE_MODELS: dict = {}
+
+
+def device_model(model: Model, device) -> DeviceModel:
+    """One uploaded copy of a model per (model object, device)."""
+    key = (id(model), str(device))
+    dm = _DEVICE_MODELS.get(key)
+    if dm is None or dm.model is not model:
+        dm = DeviceModel(model, device)
+        dm.problem_cache = {}
+        _DEVICE_MODELS[key] = dm
+    return dm
+
+
+class Configuration:
+    def __init__(self, model: Model, q=None, device="cuda:0"):
+        self.model = model
+        self.device = torch.device(device)
+        self.dmodel = device_model(model, self.device)
+        self.batched = False
+        self._q = torch.tensor(model.qpos0[None, :], dtype=torch.float64, device=self.device)
+        self.update(q)
+
+    # ---- state -------------------------------------------------------------
+    def update(self, q=None) -> None:
+        """Set the configuration(s). Kinematics are evaluated on demand by the kernels, so
+        unlike the reference there is no FK cache to refresh."""
+        if q is None:
+            return
+        if isinstance(q, torch.Tensor):
+            t = q.detach().to(device=self.device, dtype=torch.float64)
+        else:
+            t = torch.tensor(np.asarray(q, dtype=np.float64), device=self.device)
+        if t.ndim == 1:
+            self.batched = False
+            t = t[None, :]
+        elif t.ndim == 2:
+            self.batched = True
+        else:
+            raise ValueError(f"q must have shape ({self.model.nq},) or (B, {self.model.nq})")
+        if t.shape[1] != self.model.nq:
+            raise ValueError(f"q must have {self.model.nq} entries per configuration, got {t.shape[1]}")
+        self._q = t.contiguous().clone()
+
+    def update_from_keyframe(self, key_name: str) -> None:
+        key_id = self.model.key_id(key_name)
+        if key_id == -1:
+            raise exceptions.InvalidKeyframe(key_name, self.model)
+        self.update(q=self.model.key_qpos[key_id])
+
+    @property
+    def batch_size(self) -> int:
+        return self._q.shape[0]
+
+    def _out(self, t: torch.Tensor):
+        return t if self.batched else t[0].cpu().numpy()
+
+    @property
+    def q(self):
+        """Copy of the configuration vector(s)."""
+        return self._out(self._q.clone())
+
+    @property
+    def q_tensor(self) -> torch.Tensor:
+        """The device tensor [B, nq] itself (no copy)."""
+        return self._q
+
+    @property
+    def nv(self) -> int:
+        return self.model.nv
+
+    @property
+    def nq(self) -> int:
+        return self.model.nq
+
+    # ---- limits ------------------------------------------------------------
+    def check_limits(self, tol: float = 1e-6, safety_break: bool = True) -> None:
+        """Raise (or warn) when a limited non-free joint is outside [lower - tol, upper + tol].
+        For a batch, the first offending configuration is reported."""
+        first = self.dmodel.first_limit_violation(self._q, tol)
+        bad = torch.nonzero(first >= 0)
+        if bad.numel() == 0:
+            return
+        b = int(bad[0, 0])
+        jnt = int(first[b])
+        qval = float(self._q[b, self.model.jnt_qposadr[jnt]])
+        qmin, qmax = (float(x) for x in self.model.jnt_range[jnt])
+        if safety_break:
+            raise exceptions.NotWithinConfigurationLimits(joint_id=jnt, value=qval, lower=qmin, upper=qmax,
+                                                          model=self.model)
+        extra = f" (configuration {b}; {bad.shape[0]} of {self.batch_size} configurations violate limits)" \
+            if self.batched else ""
+        logging.warning(f"Value {qval:.2f} at index {jnt} is outside of its limits: [{qmin:.2f}, {qmax:.2f}]{extra}")
+
+    # ---- frames ------------------------------------------------------------
+    def _frame_id(self, frame_name: str, frame_type: str) -> int:
+        if frame_type not in consts.SUPPORTED_FRAMES:
+            raise exceptions.UnsupportedFrame(frame_type, consts.SUPPORTED_FRAMES)
+        fid = {"body": self.model.body_id, "geom": self.model.geom_id, "site": self.model.site_id}[frame_type](frame_name)
+        if fid == -1:
+            raise exceptions.InvalidFrame(frame_name=frame_name, frame_type=frame_type, model=self.model)
+        return fid
+
+    def get_frame_jacobian(self, frame_name: str, frame_type: str):
+        """Body-frame Jacobian [.., 6, nv], rows (linear; angular)."""
+        fid = self._frame_id(frame_name, frame_type)
+        return self._out(self.dmodel.frame_jacobian(self._q, consts.FRAME_TO_ENUM[frame_type], fid))
+
+    def get_transform_frame_to_world(self, frame_name: str, frame_type: str) -> SE3:
+        fid = self._frame_id(frame_name, frame_type)
+        pose = self.dmodel.frame_pose(self._q, consts.FRAME_TO_ENUM[frame_type], fid)
+        return SE3(pose if self.batched else pose[0].cpu())
+
+    def get_transform(self, source_name: str, source_type: str, dest_name: str, dest_type: str) -> SE3:
+        T_src = self.get_transform_frame_to_world(source_name, source_type)
+        T_dst = self.get_transform_frame_to_world(dest_name, dest_type)
+        return T_dst.inverse() @ T_src
+
+    # ---- integration ---------------------------------------------------------
+    def _velocity(self, velocity) -> torch.Tensor:
+        if isinstance(velocity, torch.Tensor):
+            v = velocity.detach().to(device=self.device, dtype=torch.float64)
+        else:
+            v = torch.tensor(np.asarray(velocity, dtype=np.float64), device=self.device)
+        if v.ndim == 1:
+            v = v[None, :].expand(self.batch_size, -1)
+        if tuple(v.shape) != (self.batch_size, self.model.nv):
+            raise ValueError(f"velocity must have shape (.., {self.model.nv})")
+        return v.contiguous()
+
+    def integrate(self, velocity, dt: float):
+        """q (+) dt * v without modifying the configuration."""
+        q = self._q.clone()
+        self.dmodel.integrate_(q, self._velocity(velocity), dt)
+        return self._out(q)
+
+    def integrate_inplace(self, velocity, dt: float) -> None:
+        self.dmodel.integrate_(self._q, self._velocity(velocity), dt)

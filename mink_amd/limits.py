@@ -1,0 +1,163 @@
+"""Kinematic limits of the host API (reference: mink/limits/*.py)."""
+from __future__ import annotations
+
+from typing import Mapping, NamedTuple, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from .constants import dof_width
+from .exceptions import LimitDefinitionError
+from .mjcf import JNT_FREE, MJ_MAXVAL
+
+
+class Constraint(NamedTuple):
+    r"""Linear inequality :math:`G(q) \Delta q \leq h(q)`; inactive if both are None."""
+    G: Optional[object] = None
+    h: Optional[object] = None
+
+    @property
+    def inactive(self) -> bool:
+        return self.G is None and self.h is None
+
+
+class Limit:
+    """Base class; subclasses lower themselves to a ``mk_limit_desc``."""
+
+    def _spec(self, model) -> Optional[dict]:
+        raise NotImplementedError
+
+    def compute_qp_inequalities(self, configuration, dt: float) -> Constraint:
+        from .solve_ik import get_problem
+        spec = self._spec(configuration.model)
+        if spec is None:
+            return Constraint()
+        prob, _ = get_problem(configuration, [], [self])
+        _, _, G, h = prob.build_qp(configuration.q_tensor, None, dt, 0.0)
+        return Constraint(G=configuration._out(G), h=configuration._out(h))
+
+
+class ConfigurationLimit(Limit):
+    """Joint position limits; floating-base joints are ignored
+    (mink/limits/configuration_limit.py)."""
+
+    def __init__(self, model, gain: float = 0.95, min_distance_from_limits: float = 0.0):
+        if not 0.0 < gain <= 1.0:
+            raise LimitDefinitionError(f"{self.__class__.__name__} gain must be in the range (0, 1]")
+        index_list: list = []
+        lower = np.full(model.nq, -MJ_MAXVAL)
+        upper = np.full(model.nq, MJ_MAXVAL)
+        for jnt in range(model.njnt):
+            jt = int(model.jnt_type[jnt])
+            if jt == JNT_FREE or not model.jnt_limited[jnt]:
+                continue
+            padr = model.jnt_qposadr[jnt]
+            lower[padr] = model.jnt_range[jnt, 0] + min_distance_from_limits
+            upper[padr] = model.jnt_range[jnt, 1] - min_distance_from_limits
+            vadr = model.jnt_dofadr[jnt]
+            index_list.extend(range(vadr, vadr + dof_width(jt)))
+        self.indices = np.array(index_list, dtype=np.int64)
+        self.indices.setflags(write=False)
+        self.projection_matrix = np.eye(model.nv)[self.indices] if len(self.indices) > 0 else None
+        self.lower, self.upper = lower, upper
+        self.model = model
+        self.gain = gain
+        self.min_distance_from_limits = min_distance_from_limits
+
+    def _spec(self, model):
+        if self.projection_matrix is None:
+            return None
+        return dict(type=L.LIMIT_CONFIGURATION, gain=self.gain,
+                    min_distance_from_limits=self.min_distance_from_limits)
+
+
+class VelocityLimit(Limit):
+    """Joint velocity limits (mink/limits/velocity_limit.py); ``velocities`` maps joint
+    name to the maximum magnitude."""
+
+    def __init__(self, model, velocities: Mapping[str, object] = {}):
+        limit_list: list = []
+        index_list: list = []
+        for joint_name, max_vel in velocities.items():
+            jid = model.joint_id(joint_name)
+            if jid < 0:
+                raise LimitDefinitionError(f"Joint {joint_name} does not exist in the model")
+            jt = int(model.jnt_type[jid])
+            if jt == JNT_FREE:
+                raise LimitDefinitionError(f"Free joint {joint_name} is not supported")
+            vadr = model.jnt_dofadr[jid]
+            vdim = dof_width(jt)
+            max_vel = np.atleast_1d(max_vel)
+            if max_vel.shape != (vdim,):
+                raise LimitDefinitionError(f"Joint {joint_name} must have a limit of shape ({vdim},). "
+                                           f"Got: {max_vel.shape}")
+            index_list.extend(range(vadr, vadr + vdim))
+            limit_list.extend(max_vel.tolist())
+        self.indices = np.array(index_list, dtype=np.int64)
+        self.indices.setflags(write=False)
+        self.limit = np.array(limit_list, dtype=np.float64)
+        self.limit.setflags(write=False)
+        self.projection_matrix = np.eye(model.nv)[self.indices] if len(self.indices) > 0 else None
+
+    def _spec(self, model):
+        if self.projection_matrix is None:
+            return None
+        return dict(type=L.LIMIT_VELOCITY, index=self.indices.astype(np.int32), vmax=np.array(self.limit))
+
+
+def _allowed(model, a: int, b: int) -> bool:
+    """Pair filters of mink/limits/collision_avoidance_limit.py:75-115: not welded
+    together, not parent / child, and passing the contype / conaffinity test."""
+    ba, bb = model.geom_bodyid[a], model.geom_bodyid[b]
+    wa, wb = model.body_weldid[ba], model.body_weldid[bb]
+    if wa == wb:
+        return False
+    pwa = model.body_weldid[model.body_parentid[wa]]
+    pwb = model.body_weldid[model.body_parentid[wb]]
+    if wa == pwb or wb == pwa:
+        return False
+    return bool(model.geom_contype[a] & model.geom_conaffinity[b]) or \
+        bool(model.geom_contype[b] & model.geom_conaffinity[a])
+
+
+class CollisionAvoidanceLimit(Limit):
+    """Normal-velocity limit between geom pairs (mink/limits/collision_avoidance_limit.py).
+    Distances are available for plane / sphere / box primitives."""
+
+    def __init__(self, model, geom_pairs: Sequence, gain: float = 0.85,
+                 minimum_distance_from_collisions: float = 0.005, collision_detection_distance: float = 0.01,
+                 bound_relaxation: float = 0.0):
+        self.model = model
+        self.gain = gain
+        self.minimum_distance_from_collisions = minimum_distance_from_collisions
+        self.collision_detection_distance = collision_detection_distance
+        self.bound_relaxation = bound_relaxation
+        self.geom_id_pairs = self._construct_geom_id_pairs(geom_pairs)
+        self.max_num_contacts = len(self.geom_id_pairs)
+
+    def _ids(self, group) -> list:
+        out = []
+        for g in group:
+            if isinstance(g, (int, np.integer)):
+                out.append(int(g))
+            else:
+                gid = self.model.geom_id(g)
+                if gid < 0:
+                    raise LimitDefinitionError(f"geom '{g}' does not exist in the model")
+                out.append(gid)
+        return list(set(out))
+
+    def _construct_geom_id_pairs(self, geom_pairs):
+        pairs = []
+        for group_a, group_b in geom_pairs:
+            for a in self._ids(group_a):
+                for b in self._ids(group_b):
+                    if _allowed(self.model, a, b):
+                        pairs.append((min(a, b), max(a, b)))
+        return pairs
+
+    def _spec(self, model):
+        return dict(type=L.LIMIT_COLLISION, index=np.array(self.geom_id_pairs, dtype=np.int32).reshape(-1),
+                    gain=self.gain, minimum_distance_from_collisions=self.minimum_distance_from_collisions,
+                    collision_detection_distance=self.collision_detection_distance,
+                    bound_relaxation=self.bound_relaxation)

@@ -1,0 +1,103 @@
+"""``build_ik`` / ``solve_ik`` of the host API (reference: mink/solve_ik.py:43-105) and
+the batched form of the callers' loop (interactive_scripts/teleop_mouse.py:105-121)."""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .engine import DeviceProblem
+from .limits import ConfigurationLimit, Limit
+from .tasks import Task
+
+SUPPORTED_SOLVERS = ("quadprog", "daqp", "mink_amd")
+
+
+class Problem(NamedTuple):
+    """The stacked QP, like ``qpsolvers.Problem``: min 1/2 x'Px + q'x s.t. Gx <= h."""
+    P: object
+    q: object
+    G: Optional[object]
+    h: Optional[object]
+
+    def unpack(self):
+        return self.P, self.q, self.G, self.h, None, None, None, None
+
+
+def _signature(spec: dict) -> tuple:
+    out = []
+    for k in sorted(spec):
+        v = spec[k]
+        out.append((k, np.asarray(v).tobytes() if isinstance(v, (np.ndarray, list, tuple)) else v))
+    return tuple(out)
+
+
+def get_problem(configuration, tasks: Sequence[Task], limits: Sequence[Limit]):
+    """(device problem, targets tensor) for a task / limit set; problems are cached per
+    uploaded model by the value of their descriptors."""
+    model = configuration.model
+    task_specs = [t._spec(model) for t in tasks]
+    limit_specs = [s for s in (l._spec(model) for l in limits) if s is not None]
+    # targets first: a missing target is reported before any device work
+    parts = [t._target_tensor(configuration) for t in tasks if t._target_width() > 0]
+    targets = torch.cat(parts, dim=1).contiguous() if parts else None
+    key = (tuple(_signature(s) for s in task_specs), tuple(_signature(s) for s in limit_specs))
+    cache = configuration.dmodel.problem_cache
+    prob = cache.get(key)
+    if prob is None:
+        if len(cache) > 64:
+            cache.clear()
+        prob = DeviceProblem(configuration.dmodel, task_specs, limit_specs)
+        cache[key] = prob
+    return prob, targets
+
+
+def _resolve_limits(configuration, limits):
+    if limits is None:
+        return [ConfigurationLimit(configuration.model)]
+    return list(limits)
+
+
+def build_ik(configuration, tasks: Sequence[Task], dt: float, damping: float = 1e-12,
+             limits: Optional[Sequence[Limit]] = None) -> Problem:
+    """Build the QP of the current configuration(s). ``limits=None`` means a default
+    ConfigurationLimit, ``limits=[]`` no limits (G and h are None)."""
+    prob, targets = get_problem(configuration, tasks, _resolve_limits(configuration, limits))
+    P, c, G, h = prob.build_qp(configuration.q_tensor, targets, dt, damping)
+    o = configuration._out
+    return Problem(o(P), o(c), None if G is None else o(G), None if h is None else o(h))
+
+
+def _check_solver(solver: str) -> None:
+    if solver not in SUPPORTED_SOLVERS:
+        raise ValueError(f"solver '{solver}' is not available; the exact active-set kernels answer to "
+                         f"{SUPPORTED_SOLVERS} (the minimiser of a strictly convex QP does not depend on the backend)")
+
+
+def solve_ik(configuration, tasks: Sequence[Task], dt: float, solver: str, damping: float = 1e-12,
+             safety_break: bool = False, limits: Optional[Sequence[Limit]] = None, **kwargs):
+    """Velocity ``v`` tangent to the current configuration(s): [nv] numpy for a single
+    configuration, [B, nv] device tensor for a batch."""
+    _check_solver(solver)
+    configuration.check_limits(safety_break=safety_break)
+    prob, targets = get_problem(configuration, tasks, _resolve_limits(configuration, limits))
+    v, status = prob.solve(configuration.q_tensor, targets, dt, damping)
+    assert int((status != 0).sum()) == 0, "QP solver failed (infeasible limits or non-finite input)"
+    return configuration._out(v)
+
+
+def solve_ik_iterate(configuration, tasks: Sequence[Task], dt: float, solver: str, damping: float = 1e-12,
+                     max_iters: int = 20, pos_threshold: float = 1e-4, ori_threshold: float = 1e-4,
+                     limits: Optional[Sequence[Limit]] = None) -> dict:
+    """The callers' loop on the GPU: up to ``max_iters`` x (solve_ik, integrate_inplace,
+    frame-task error), each configuration leaving the loop when its frame task error is
+    below the thresholds.  Updates the configuration in place and returns
+    ``dict(iters, err, status, v)``.  Needs a problem the fused kernels serve (one
+    FrameTask, posture-like tasks, Configuration / Velocity limits)."""
+    _check_solver(solver)
+    prob, targets = get_problem(configuration, tasks, _resolve_limits(configuration, limits))
+    res = prob.iterate_(configuration.q_tensor, targets, dt, damping, max_iters, pos_threshold, ori_threshold,
+                        want_v=True)
+    assert int((res["status"] != 0).sum()) == 0, "QP solver failed (infeasible limits or non-finite input)"
+    return {k: configuration._out(v) for k, v in res.items()}

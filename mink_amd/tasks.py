@@ -1,0 +1,293 @@
+"""Kinematic tasks of the host API (reference: mink/tasks/*.py).
+
+A task holds its parameters and target; the arithmetic -- error, Jacobian, (H, c) --
+is evaluated by the HIP kernels for the whole batch of a ``Configuration``.  Targets
+may be one pose / vector shared by the batch or one per configuration.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import constants as consts
+from . import exceptions
+from .exceptions import InvalidDamping, InvalidGain, InvalidTarget, TargetNotSet, TaskDefinitionError
+from .lie import SE3
+from .mjcf import JNT_FREE
+
+
+class Objective(NamedTuple):
+    r"""Quadratic objective :math:`\frac{1}{2} x^T H x + c^T x`."""
+    H: object
+    c: object
+
+    def value(self, x):
+        x = np.asarray(x)
+        H, c = np.asarray(self.H), np.asarray(self.c)
+        return x.T @ H @ x + c @ x
+
+
+class Task:
+    """Base class: cost / gain / lm_damping validation as in mink/tasks/task.py:54-79."""
+
+    def __init__(self, cost: np.ndarray, gain: float = 1.0, lm_damping: float = 0.0):
+        if not 0.0 <= gain <= 1.0:
+            raise InvalidGain("`gain` must be in the range [0, 1]")
+        if lm_damping < 0.0:
+            raise InvalidDamping("`lm_damping` must be >= 0")
+        self.cost = cost
+        self.gain = gain
+        self.lm_damping = lm_damping
+
+    # -- lowering to the C ABI ------------------------------------------------
+    def _spec(self, model) -> dict:
+        raise NotImplementedError
+
+    def _target_width(self) -> int:
+        return 0
+
+    def _target_tensor(self, configuration) -> Optional[torch.Tensor]:
+        return None
+
+    def _k(self, model) -> int:
+        raise NotImplementedError
+
+    def _problem(self, configuration):
+        from .solve_ik import get_problem
+        return get_problem(configuration, [self], [])
+
+    def compute_error(self, configuration):
+        prob, targets = self._problem(configuration)
+        err, _ = prob.task_eval(0, self._k(configuration.model), configuration.q_tensor, targets)
+        return configuration._out(err)
+
+    def compute_jacobian(self, configuration):
+        prob, targets = self._problem(configuration)
+        _, jac = prob.task_eval(0, self._k(configuration.model), configuration.q_tensor, targets)
+        return configuration._out(jac)
+
+    def compute_qp_objective(self, configuration) -> Objective:
+        prob, targets = self._problem(configuration)
+        P, c, _, _ = prob.build_qp(configuration.q_tensor, targets, 1.0, 0.0)
+        return Objective(configuration._out(P), configuration._out(c))
+
+
+def _pose_target(pose: SE3, configuration, cls_name: str) -> torch.Tensor:
+    if pose is None:
+        raise TargetNotSet(cls_name)
+    t = pose.wxyz_xyz.to(device=configuration.device, dtype=torch.float64)
+    if t.ndim == 1:
+        t = t[None, :].expand(configuration.batch_size, -1)
+    if tuple(t.shape) != (configuration.batch_size, 7):
+        raise InvalidTarget(f"Expected {configuration.batch_size} target poses but got {tuple(t.shape)}")
+    return t
+
+
+class _FrameCosts(Task):
+    k = 6
+
+    def set_position_cost(self, position_cost) -> None:
+        position_cost = np.atleast_1d(position_cost)
+        if position_cost.ndim != 1 or position_cost.shape[0] not in (1, 3):
+            raise TaskDefinitionError(
+                f"{self.__class__.__name__} position cost should be a vector of shape 1 (aka identical cost for all "
+                f"coordinates) or (3,) but got {position_cost.shape}")
+        if not np.all(position_cost >= 0.0):
+            raise TaskDefinitionError(f"{self.__class__.__name__} position cost should be >= 0")
+        self.cost[:3] = position_cost
+
+    def set_orientation_cost(self, orientation_cost) -> None:
+        orientation_cost = np.atleast_1d(orientation_cost)
+        if orientation_cost.ndim != 1 or orientation_cost.shape[0] not in (1, 3):
+            raise TaskDefinitionError(
+                f"{self.__class__.__name__} orientation cost should be a vector of shape 1 (aka identical cost for "
+                f"all coordinates) or (3,) but got {orientation_cost.shape}")
+        if not np.all(orientation_cost >= 0.0):
+            raise TaskDefinitionError(f"{self.__class__.__name__} position cost should be >= 0")
+        self.cost[3:] = orientation_cost
+
+    def _k(self, model) -> int:
+        return 6
+
+    def _target_width(self) -> int:
+        return 7
+
+
+def _frame_ids(model, name, ftype):
+    if ftype not in consts.SUPPORTED_FRAMES:
+        raise exceptions.UnsupportedFrame(ftype, consts.SUPPORTED_FRAMES)
+    fid = {"body": model.body_id, "geom": model.geom_id, "site": model.site_id}[ftype](name)
+    if fid == -1:
+        raise exceptions.InvalidFrame(frame_name=name, frame_type=ftype, model=model)
+    return consts.FRAME_TO_ENUM[ftype], fid
+
+
+class FrameTask(_FrameCosts):
+    """Regulate the pose of a frame in the world frame (mink/tasks/frame_task.py)."""
+
+    def __init__(self, frame_name: str, frame_type: str, position_cost, orientation_cost, gain: float = 1.0,
+                 lm_damping: float = 0.0):
+        super().__init__(cost=np.zeros((self.k,)), gain=gain, lm_damping=lm_damping)
+        self.frame_name = frame_name
+        self.frame_type = frame_type
+        self.position_cost = position_cost
+        self.orientation_cost = orientation_cost
+        self.transform_target_to_world: Optional[SE3] = None
+        self.set_position_cost(position_cost)
+        self.set_orientation_cost(orientation_cost)
+
+    def set_target(self, transform_target_to_world: SE3) -> None:
+        self.transform_target_to_world = transform_target_to_world.copy()
+
+    def set_target_from_configuration(self, configuration) -> None:
+        self.set_target(configuration.get_transform_frame_to_world(self.frame_name, self.frame_type))
+
+    def _spec(self, model) -> dict:
+        ft, fid = _frame_ids(model, self.frame_name, self.frame_type)
+        return dict(type=L.TASK_FRAME, frame_type=ft, frame_id=fid, cost=self.cost.copy(), gain=self.gain,
+                    lm_damping=self.lm_damping)
+
+    def _target_tensor(self, configuration):
+        return _pose_target(self.transform_target_to_world, configuration, self.__class__.__name__)
+
+
+class RelativeFrameTask(_FrameCosts):
+    """Regulate the pose of a frame relative to another frame (mink/tasks/relative_frame_task.py)."""
+
+    def __init__(self, frame_name: str, frame_type: str, root_name: str, root_type: str, position_cost,
+                 orientation_cost, gain: float = 1.0, lm_damping: float = 0.0):
+        super().__init__(cost=np.zeros((self.k,)), gain=gain, lm_damping=lm_damping)
+        self.frame_name, self.frame_type = frame_name, frame_type
+        self.root_name, self.root_type = root_name, root_type
+        self.position_cost = position_cost
+        self.orientation_cost = orientation_cost
+        self.transform_target_to_root: Optional[SE3] = None
+        self.set_position_cost(position_cost)
+        self.set_orientation_cost(orientation_cost)
+
+    def set_target(self, transform_target_to_root: SE3) -> None:
+        self.transform_target_to_root = transform_target_to_root.copy()
+
+    def set_target_from_configuration(self, configuration) -> None:
+        self.set_target(configuration.get_transform(self.frame_name, self.frame_type, self.root_name, self.root_type))
+
+    def _spec(self, model) -> dict:
+        ft, fid = _frame_ids(model, self.frame_name, self.frame_type)
+        rt, rid = _frame_ids(model, self.root_name, self.root_type)
+        return dict(type=L.TASK_RELATIVE_FRAME, frame_type=ft, frame_id=fid, root_type=rt, root_id=rid,
+                    cost=self.cost.copy(), gain=self.gain, lm_damping=self.lm_damping)
+
+    def _target_tensor(self, configuration):
+        return _pose_target(self.transform_target_to_root, configuration, self.__class__.__name__)
+
+
+class PostureTask(Task):
+    """Regulate joint angles towards a posture; floating-base dofs are unaffected
+    (mink/tasks/posture_task.py)."""
+
+    def __init__(self, model, cost, gain: float = 1.0, lm_damping: float = 0.0):
+        super().__init__(cost=np.zeros((model.nv,)), gain=gain, lm_damping=lm_damping)
+        self.target_q: Optional[np.ndarray] = None
+        self.k = model.nv
+        self.nq = model.nq
+        self.set_cost(cost)
+
+    def set_cost(self, cost) -> None:
+        cost = np.atleast_1d(cost)
+        if cost.ndim != 1 or cost.shape[0] not in (1, self.k):
+            raise TaskDefinitionError(
+                f"{self.__class__.__name__} cost must be a vector of shape (1,) (aka identical cost for all dofs) "
+                f"or ({self.k},). Got {cost.shape}")
+        if not np.all(cost >= 0.0):
+            raise TaskDefinitionError(f"{self.__class__.__name__} cost should be >= 0")
+        self.cost[: self.k] = cost
+
+    def set_target(self, target_q) -> None:
+        if isinstance(target_q, torch.Tensor):
+            target_q = target_q.detach().cpu().numpy()
+        target_q = np.atleast_1d(target_q)
+        if target_q.ndim != 1 or target_q.shape[0] != (self.nq):
+            raise InvalidTarget(f"Expected target posture to have shape ({self.nq},) but got {target_q.shape}")
+        self.target_q = target_q.copy()
+
+    def set_target_from_configuration(self, configuration) -> None:
+        q = configuration.q
+        if configuration.batched:
+            if configuration.batch_size != 1:
+                raise InvalidTarget("the posture target is shared by the batch: pass a single configuration")
+            q = q[0]
+        self.set_target(q)
+
+    def _k(self, model) -> int:
+        return model.nv
+
+    def _spec(self, model) -> dict:
+        if self.target_q is None:
+            raise TargetNotSet(self.__class__.__name__)
+        return dict(type=L.TASK_POSTURE, cost=self.cost.copy(), target_q=np.asarray(self.target_q, dtype=np.float64),
+                    gain=self.gain, lm_damping=self.lm_damping)
+
+
+class DampingTask(PostureTask):
+    """Minimise joint velocities: a posture task with gain 0 and target qpos0
+    (mink/tasks/damping_task.py)."""
+
+    def __init__(self, model, cost):
+        super().__init__(model=model, cost=cost, gain=0.0, lm_damping=0.0)
+        self.target_q = model.qpos0
+
+
+class ComTask(Task):
+    """Regulate the centre of mass of the subtree of body 1 (mink/tasks/com_task.py)."""
+    k = 3
+
+    def __init__(self, cost, gain: float = 1.0, lm_damping: float = 0.0):
+        super().__init__(cost=np.zeros((self.k,)), gain=gain, lm_damping=lm_damping)
+        self.target_com = None
+        self.set_cost(cost)
+
+    def set_cost(self, cost) -> None:
+        cost = np.atleast_1d(cost)
+        if cost.ndim != 1 or cost.shape[0] not in (1, self.k):
+            raise TaskDefinitionError(
+                f"{self.__class__.__name__} cost must be a vector of shape (1,) (aka identical cost for all "
+                f"coordinates) or ({self.k},). Got {cost.shape}")
+        if not np.all(cost >= 0.0):
+            raise TaskDefinitionError(f"{self.__class__.__name__} cost must be >= 0")
+        self.cost[:] = cost
+
+    def set_target(self, target_com) -> None:
+        if isinstance(target_com, torch.Tensor):
+            target_com = target_com.detach().cpu().numpy()
+        target_com = np.atleast_1d(target_com)
+        if target_com.shape[-1] != self.k or target_com.ndim > 2:
+            raise InvalidTarget(f"Expected target CoM to have shape ({self.k},) but got {target_com.shape}")
+        self.target_com = target_com.copy()
+
+    def set_target_from_configuration(self, configuration) -> None:
+        saved, self.target_com = self.target_com, np.zeros(3)
+        try:
+            com = self.compute_error(configuration)   # error with a zero target is the CoM itself
+        finally:
+            self.target_com = saved
+        self.set_target(com.cpu().numpy() if isinstance(com, torch.Tensor) else com)
+
+    def _k(self, model) -> int:
+        return 3
+
+    def _target_width(self) -> int:
+        return 3
+
+    def _spec(self, model) -> dict:
+        return dict(type=L.TASK_COM, cost=self.cost.copy(), gain=self.gain, lm_damping=self.lm_damping)
+
+    def _target_tensor(self, configuration):
+        if self.target_com is None:
+            raise TargetNotSet(self.__class__.__name__)
+        t = torch.tensor(np.asarray(self.target_com, dtype=np.float64), device=configuration.device)
+        if t.ndim == 1:
+            t = t[None, :].expand(configuration.batch_size, -1)
+        return t

@@ -1,0 +1,203 @@
+"""The mink-named host API on the GPU against the golden vectors captured from the
+reference: the same calls the reference's callers and tests make, on one configuration
+(numpy in / out) and on a batch (device tensors)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+import mink_amd as mink
+from mink_amd.mjcf import load_builtin
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def model():
+    assert torch.cuda.is_available()
+    return load_builtin("tidybot_cube")
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "tidybot_build_ik.npz"))
+
+
+def make_tasks(model, g, target):
+    frame = mink.FrameTask("pinch_site", "site", position_cost=1.0, orientation_cost=1.0, lm_damping=1.0)
+    frame.set_target(target)
+    posture = mink.PostureTask(model, cost=g["posture_cost"])
+    posture.set_target(g["home"])
+    damping = mink.DampingTask(model, g["damping_cost"])
+    limits = [mink.ConfigurationLimit(model),
+              mink.VelocityLimit(model, dict(zip(g["vel_names"].tolist(), g["vel_limits"].tolist())))]
+    return frame, posture, damping, limits
+
+
+def same_pose(a, b, tol=1e-12):
+    a, b = np.asarray(a), np.asarray(b)
+    s = np.sign(np.sum(a[..., :4] * b[..., :4], axis=-1, keepdims=True))
+    np.testing.assert_allclose(a[..., :4] * s, b[..., :4], rtol=0, atol=tol)
+    np.testing.assert_allclose(a[..., 4:], b[..., 4:], rtol=0, atol=tol)
+
+
+def test_single_configuration_matches_reference(model, g):
+    dt = float(g["dt"])
+    for i in (0, 1, 3, 5, 11):
+        cfg = mink.Configuration(model, g["q"][i])
+        assert not cfg.batched and cfg.q.shape == (model.nq,)
+        frame, posture, damping, limits = make_tasks(model, g, mink.SE3(g["target"][i]))
+        same_pose(cfg.get_transform_frame_to_world("pinch_site", "site").wxyz_xyz.numpy(), g["site_pose"][i])
+        np.testing.assert_allclose(cfg.get_frame_jacobian("pinch_site", "site"), g["frame_jac"][i], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(frame.compute_error(cfg), g["frame_err"][i], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(frame.compute_jacobian(cfg), g["frame_task_jac"][i], rtol=0, atol=1e-11)
+        for name, task in (("frame", frame), ("posture", posture), ("damping", damping)):
+            H, c = task.compute_qp_objective(cfg)
+            np.testing.assert_allclose(H, g["H_" + name][i], rtol=0, atol=1e-11)
+            np.testing.assert_allclose(c, g["c_" + name][i], rtol=0, atol=1e-11)
+        G, h = limits[0].compute_qp_inequalities(cfg, dt)
+        np.testing.assert_allclose(G, g["G_cfg"][i], rtol=0, atol=0)
+        np.testing.assert_allclose(h, g["h_cfg"][i], rtol=0, atol=1e-14)
+        G, h = limits[1].compute_qp_inequalities(cfg, dt)
+        np.testing.assert_allclose(G, g["G_vel"][i], rtol=0, atol=0)
+        np.testing.assert_allclose(h, g["h_vel"][i], rtol=0, atol=1e-15)
+        tasks = [frame, posture, damping]
+        prob = mink.build_ik(cfg, tasks, dt, 1e-3, limits)
+        np.testing.assert_allclose(prob.P, g["P"][i], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(prob.q, g["c"][i], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(prob.G, g["G"][i], rtol=0, atol=0)
+        np.testing.assert_allclose(prob.h, g["h"][i], rtol=0, atol=1e-14)
+        v = mink.solve_ik(cfg, tasks, dt, "quadprog", 1e-3, limits=limits)
+        assert isinstance(v, np.ndarray) and v.shape == (model.nv,)
+        np.testing.assert_allclose(v, g["v"][i], rtol=0, atol=TOL)
+        np.testing.assert_allclose(cfg.integrate(v, dt), g["q_next"][i], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(mink.solve_ik(cfg, [frame, posture], dt, "quadprog", 1e-3), g["v_default_limit"][i],
+                                   rtol=0, atol=TOL)
+        np.testing.assert_allclose(mink.solve_ik(cfg, [frame, posture], dt, "quadprog", 1e-3, limits=[]),
+                                   g["v_nolimit"][i], rtol=0, atol=TOL)
+        assert mink.build_ik(cfg, [frame, posture], dt, 1e-3, limits=[]).G is None
+
+
+def test_batched_configuration_matches_reference(model, g):
+    dt = float(g["dt"])
+    cfg = mink.Configuration(model, g["q"])
+    assert cfg.batched and cfg.batch_size == 24
+    frame, posture, damping, limits = make_tasks(model, g, mink.SE3(torch.tensor(g["target"])))
+    tasks = [frame, posture, damping]
+    v = mink.solve_ik(cfg, tasks, dt, "quadprog", 1e-3, limits=limits)
+    assert isinstance(v, torch.Tensor) and v.is_cuda
+    np.testing.assert_allclose(v.cpu().numpy(), g["v"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(frame.compute_error(cfg).cpu().numpy(), g["frame_err"], rtol=0, atol=1e-12)
+    prob = mink.build_ik(cfg, tasks, dt, 1e-3, limits)
+    np.testing.assert_allclose(prob.P.cpu().numpy(), g["P"], rtol=0, atol=1e-11)
+    cfg.integrate_inplace(v, dt)
+    np.testing.assert_allclose(cfg.q.cpu().numpy(), g["q_next"], rtol=0, atol=1e-12)
+    # relative frame and centre of mass (wave-per-problem kernels)
+    cfg.update(g["q"])
+    rel = mink.RelativeFrameTask("pinch_site", "site", "base_link", "body", position_cost=[1.0, 2.0, 0.5],
+                                 orientation_cost=0.7, gain=0.8, lm_damping=0.5)
+    rel.set_target(mink.SE3(torch.tensor(g["rel_target"])))
+    np.testing.assert_allclose(rel.compute_error(cfg).cpu().numpy(), g["rel_err"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(rel.compute_jacobian(cfg).cpu().numpy(), g["rel_jac"], rtol=0, atol=1e-11)
+    H, c = rel.compute_qp_objective(cfg)
+    np.testing.assert_allclose(H.cpu().numpy(), g["H_rel"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(mink.solve_ik(cfg, [rel, posture], dt, "quadprog", 1e-3, limits=limits).cpu().numpy(),
+                               g["v_rel"], rtol=0, atol=TOL)
+    com = mink.ComTask(cost=[1.0, 1.0, 0.5])
+    com.set_target(np.zeros(3))
+    err0 = com.compute_error(cfg).cpu().numpy()          # CoM itself
+    np.testing.assert_allclose(com.compute_jacobian(cfg).cpu().numpy(), g["com_jac"], rtol=0, atol=1e-12)
+    com.set_target_from_configuration(cfg)
+    np.testing.assert_allclose(com.target_com, err0, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(com.compute_error(cfg).cpu().numpy(), 0.0, atol=1e-14)
+
+
+def test_caller_loop(model, golden_dir):
+    """teleop_mouse.py's loop written against the API, and its one-launch form."""
+    g = np.load(os.path.join(golden_dir, "tidybot_loop.npz"))
+    dt = float(g["dt"])
+    posture = mink.PostureTask(model, cost=g["posture_cost"])
+    posture.set_target(g["home"])
+    k = 2
+    cfg = mink.Configuration(model, g["q0"][k])
+    frame = mink.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0)
+    frame.set_target(mink.SE3(g["target"][k]))
+    n = 0
+    for it in range(20):
+        v = mink.solve_ik(cfg, [frame, posture], dt, "quadprog", 1e-3)
+        cfg.integrate_inplace(v, dt)
+        e = frame.compute_error(cfg)
+        np.testing.assert_allclose(v, g["v"][k, it], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(cfg.q, g["q"][k, it], rtol=0, atol=1e-11)
+        n = it + 1
+        if np.linalg.norm(e[:3]) <= 1e-4 and np.linalg.norm(e[3:]) <= 1e-4:
+            break
+    assert n == int(g["iters"][k])
+    cfg = mink.Configuration(model, g["q0"])
+    frame.set_target(mink.SE3(torch.tensor(g["target"])))
+    res = mink.solve_ik_iterate(cfg, [frame, posture], dt, "quadprog", 1e-3, max_iters=20)
+    iters = res["iters"].cpu().numpy()
+    np.testing.assert_array_equal(iters, g["iters"])
+    for b, n in enumerate(iters):
+        np.testing.assert_allclose(cfg.q[b].cpu().numpy(), g["q"][b, n - 1], rtol=0, atol=1e-11)
+
+
+def test_collision_limit_api(model, golden_dir):
+    g = np.load(os.path.join(golden_dir, "collision.npz"))
+    pads = ["right_pad1", "right_pad2", "left_pad1", "left_pad2"]
+    lim = mink.CollisionAvoidanceLimit(model, [(pads, ["cube_geom", "floor"])])
+    cfg = mink.Configuration(model, g["q"])
+    G, h = lim.compute_qp_inequalities(cfg, float(g["dt"]))
+    G, h = G.cpu().numpy(), h.cpu().numpy()
+    fin = np.isfinite(g["h"])
+    np.testing.assert_array_equal(np.isfinite(h), fin)
+    np.testing.assert_allclose(h[fin], g["h"][fin], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(G, g["G"], rtol=0, atol=1e-9)
+
+
+def test_errors_and_limit_check(model, golden_dir):
+    with open(os.path.join(golden_dir, "api_strings.json")) as f:
+        strings = json.load(f)
+    cfg = mink.Configuration(model)
+
+    def raised(fn):
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001
+            return [type(e).__name__, str(e)]
+        return None
+
+    q_bad = model.key_qpos[0].copy()
+    q_bad[4] = 3.0
+    cases = {
+        "frame_no_target": lambda: mink.FrameTask("pinch_site", "site", 1.0, 1.0).compute_error(cfg),
+        "posture_no_target": lambda: mink.PostureTask(model, cost=1.0).compute_error(cfg),
+        "com_no_target": lambda: mink.ComTask(cost=1.0).compute_error(cfg),
+        "rel_no_target": lambda: mink.RelativeFrameTask("pinch_site", "site", "base_link", "body", 1.0,
+                                                        1.0).compute_error(cfg),
+        "unsupported_frame": lambda: cfg.get_frame_jacobian("pinch_site", "joint"),
+        "invalid_frame": lambda: cfg.get_frame_jacobian("nope", "site"),
+        "invalid_keyframe": lambda: cfg.update_from_keyframe("nope"),
+        "limits_violated": lambda: mink.Configuration(model, q_bad).check_limits(),
+        "limits_violated_within_tol": lambda: mink.Configuration(
+            model, np.where(np.arange(model.nq) == 4, 2.24 + 5e-7, model.key_qpos[0])).check_limits(),
+    }
+    for name, fn in cases.items():
+        assert raised(fn) == strings[name], name
+    # solve_ik only breaks when asked to (mink/solve_ik.py:99)
+    frame = mink.FrameTask("pinch_site", "site", 1.0, 1.0)
+    bad = mink.Configuration(model, np.where(np.arange(model.nq) == 4, 2.24 + 1e-3, model.key_qpos[0]))
+    frame.set_target_from_configuration(bad)
+    with pytest.raises(mink.NotWithinConfigurationLimits):
+        mink.solve_ik(bad, [frame], 0.005, "quadprog", 1e-3, safety_break=True)
+    v = mink.solve_ik(bad, [frame], 0.005, "quadprog", 1e-3, safety_break=False)
+    assert v[3] < 0.0                                  # pushed back inside the range
+    with pytest.raises(ValueError):
+        mink.solve_ik(cfg, [frame], 0.005, "osqp", 1e-3)
+    cfg.update_from_keyframe("home")
+    np.testing.assert_array_equal(cfg.q, model.key_qpos[model.key_id("home")])
