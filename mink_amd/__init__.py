@@ -30,7 +30,13 @@ def __getattr__(name):
     if mod is None:
         raise AttributeError(f"module 'mink_amd' has no attribute '{name}'")
     import importlib
-    return getattr(importlib.import_module(f".{mod}", __name__), name)
+    module = importlib.import_module(f".{mod}", __name__)
+    # bind every public name of that module on the package: the import above has just set
+    # the attribute `solve_ik` to the submodule, which must not shadow the function
+    for public, owner in _GPU_NAMES.items():
+        if owner == mod:
+            globals()[public] = getattr(module, public)
+    return globals()[name]
 
 
 __all__ = tuple(_GPU_NAMES) + (

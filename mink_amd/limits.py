@@ -28,7 +28,7 @@ class Limit:
         raise NotImplementedError
 
     def compute_qp_inequalities(self, configuration, dt: float) -> Constraint:
-        from .solve_ik import get_problem
+        from ._problems import get_problem
         spec = self._spec(configuration.model)
         if spec is None:
             return Constraint()

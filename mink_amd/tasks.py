@@ -56,7 +56,7 @@ class Task:
         raise NotImplementedError
 
     def _problem(self, configuration):
-        from .solve_ik import get_problem
+        from ._problems import get_problem
         return get_problem(configuration, [self], [])
 
     def compute_error(self, configuration):

@@ -196,7 +196,7 @@ def test_errors_and_limit_check(model, golden_dir):
     with pytest.raises(mink.NotWithinConfigurationLimits):
         mink.solve_ik(bad, [frame], 0.005, "quadprog", 1e-3, safety_break=True)
     v = mink.solve_ik(bad, [frame], 0.005, "quadprog", 1e-3, safety_break=False)
-    assert v[3] < 0.0                                  # pushed back inside the range
+    assert v[4] < 0.0                                  # pushed back inside the range
     with pytest.raises(ValueError):
         mink.solve_ik(cfg, [frame], 0.005, "osqp", 1e-3)
     cfg.update_from_keyframe("home")
