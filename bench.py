@@ -22,6 +22,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from mink_amd import sharding as S  # noqa: E402
 from mink_amd import workloads as W  # noqa: E402
 from mink_amd.engine import DeviceModel, DeviceProblem  # noqa: E402
 from mink_amd.mjcf import load_builtin  # noqa: E402
@@ -37,10 +38,9 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = 1/2 of the 157.3 TF fp32
 HBM_PEAK_GBS = 8000.0
 
 
-def make_inputs(model, dm, n, seed, device):
-    rng = np.random.default_rng(seed)
-    q0 = W.sample_q(model, rng, n)
-    qs = W.sample_q(model, rng, n)
+def make_inputs(model, dm, lo, hi, seed, device):
+    """Rows [lo, hi) of the global batch; a row's inputs do not depend on the rank count."""
+    q0, qs = S.global_rows(model, seed, lo, hi)
     site = model.site_id("pinch_site")
     targets = dm.frame_pose(torch.tensor(qs, device=device), 2, site)   # reachable SE3 targets
     return torch.tensor(q0, device=device), targets.contiguous(), q0
@@ -135,7 +135,7 @@ def main():
     prob = DeviceProblem(dm, W.task_specs(model, False), W.limit_specs(model, True))
     assert prob.fused, "headline workload must run on the fused kernel"
     B = args.shard
-    q0, targets, q0_np = make_inputs(model, dm, B, SEED * 1000 + rank, device)
+    q0, targets, q0_np = make_inputs(model, dm, rank * B, (rank + 1) * B, SEED, device)
     nbuf = args.steps + args.warmup
     qbufs = [q0.clone() for _ in range(nbuf)]
     out = dict(iters=torch.empty(B, dtype=torch.int32, device=device),
@@ -151,14 +151,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
     solves_per_rank = B * ITERS * args.steps
-    bad = int((out["status"] != 0).sum().item())
-    stats = torch.tensor([float(bad), float(out["err"][:, :3].norm(dim=1).max().item()),
-                          float(out["err"][:, 3:].norm(dim=1).max().item())], dtype=torch.float64, device=device)
-    if dist is not None:
-        s0 = stats[:1].clone()
-        dist.all_reduce(s0, op=dist.ReduceOp.SUM)
-        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-        stats[0] = s0[0]
+    stats = S.reduce_stats(
+        {"bad": int((out["status"] != 0).sum().item())},
+        {"pos": float(out["err"][:, :3].norm(dim=1).max().item()),
+         "ori": float(out["err"][:, 3:].norm(dim=1).max().item())}, dist, device)
     value = solves_per_rank * n_gpus / wall_max
     kernel_s = ev / args.steps                 # average launch duration on this rank (HIP events)
     kernel_rate = B * ITERS / kernel_s
@@ -183,8 +179,8 @@ def main():
                          "hbm": {"achieved": kernel_rate * BYTES_PER_SOLVE / 1e9, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": kernel_rate * BYTES_PER_SOLVE / 1e9 / HBM_PEAK_GBS,
                                  "bytes_per_solve": BYTES_PER_SOLVE}},
-            "solver_status_nonzero": int(stats[0].item()),
-            "final_err_max": {"pos": float(stats[1].item()), "ori": float(stats[2].item())},
+            "solver_status_nonzero": int(stats["bad"]),
+            "final_err_max": {"pos": stats["pos"], "ori": stats["ori"]},
         }
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
