@@ -227,11 +227,22 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
       s.qpos0 = m.qpos0[s.qadr];
       memcpy(s.jpos, &m.jnt_pos[3 * j], sizeof(s.jpos));
       memcpy(s.axis, &m.jnt_axis[3 * j], sizeof(s.axis));
+      {  // MuJoCo stores unit axes; make sure of it for descriptors that come from elsewhere
+        const double n = sqrt(s.axis[0] * s.axis[0] + s.axis[1] * s.axis[1] + s.axis[2] * s.axis[2]);
+        if (!(n > MK_MINVAL)) { why = "zero joint axis on the task chain"; return false; }
+        for (double& c : s.axis) c /= n;
+      }
       s.flags = 0;
+      s.pre_mat[0] = s.pre_mat[4] = s.pre_mat[8] = 1.0;
       if (j == ja) {
         s.flags |= MK_SEG_HAS_PRE;
         memcpy(s.pre_pos, ppos, sizeof(ppos));
         memcpy(s.pre_quat, pquat, sizeof(pquat));
+        if (!(pquat[0] == 1.0 && pquat[1] == 0.0 && pquat[2] == 0.0 && pquat[3] == 0.0)) {
+          s.flags |= MK_SEG_PRE_ROT;
+          const M3 Rp = q2m(Q4{pquat[0], pquat[1], pquat[2], pquat[3]});
+          memcpy(s.pre_mat, Rp.m, sizeof(s.pre_mat));
+        }
         ppos[0] = ppos[1] = ppos[2] = 0.0;
         pquat[0] = 1.0; pquat[1] = pquat[2] = pquat[3] = 0.0;
       } else {

@@ -24,7 +24,7 @@ constexpr double MK_MINVAL = 1e-15;   // MuJoCo mjMINVAL
 constexpr double MK_PI = 3.14159265358979323846;
 
 enum { MK_SEG_SLIDE = 2, MK_SEG_HINGE = 3 };
-enum { MK_SEG_HAS_PRE = 1, MK_SEG_END_BODY = 2, MK_SEG_HAS_JPOS = 4, MK_SEG_AXIS_Z = 8 };
+enum { MK_SEG_HAS_PRE = 1, MK_SEG_END_BODY = 2, MK_SEG_HAS_JPOS = 4, MK_SEG_AXIS_Z = 8, MK_SEG_PRE_ROT = 16 };
 enum { MK_TERM_CFG = 0, MK_TERM_VEL = 1 };
 enum { MK_DOF_SCALAR = 0, MK_DOF_FREE_LIN = 1, MK_DOF_FREE_ROT = 2, MK_DOF_BALL = 3 };
 
@@ -33,6 +33,7 @@ enum { MK_DOF_SCALAR = 0, MK_DOF_FREE_LIN = 1, MK_DOF_FREE_ROT = 2, MK_DOF_BALL 
 struct MkSeg {
   double pre_pos[3];
   double pre_quat[4];
+  double pre_mat[9];  // rotation matrix of pre_quat (row-major); read when MK_SEG_PRE_ROT is set
   double jpos[3];   // joint anchor in the body frame
   double axis[3];   // joint axis in the body frame
   double qpos0;
@@ -112,6 +113,37 @@ MK_DEV double mk_rsqrt(double x) {
   return 1.0 / sqrt(x);
 #endif
 }
+// sin and cos of one argument for |x| < 2^30 (joint angles, rotation-vector norms):
+// two-constant Cody-Waite reduction by pi/2 with fused multiply-adds, then the classic
+// degree-13 / degree-14 minimax kernels on [-pi/4, pi/4]; < 1 ulp.  Larger or non-finite
+// arguments give NaN, which the kernels report as non-finite input.
+MK_DEV void mk_sincos(double x, double* sn, double* cs) {
+  const double k = rint(x * 0.63661977236758134308);
+  double r = fma(-k, 1.57079632679489655800e+00, x);
+  r = fma(-k, 6.12323399573676603587e-17, r);
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double sr = fma(r * z, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const bool ok = fabs(x) < 1073741824.0;
+  const int q = ok ? (int)k : 0;
+  double s = (q & 1) ? cr : sr;
+  double c = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s : s;
+  c = ((q + 1) & 2) ? -c : c;
+  *sn = ok ? s : NAN;
+  *cs = ok ? c : NAN;
+}
+
 // True when no lane of the wave still has `pending` set.
 MK_DEV bool mk_wave_none(bool pending) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -236,7 +268,7 @@ MK_DEV Twist se3_log(Q4 q, V3 t) {
   } else {
     double th = sqrt(t2), h = 0.5 * th;
     double s, c;
-    sincos(h, &s, &c);
+    mk_sincos(h, &s, &c);
     coef = (1.0 - th * c / (2.0 * s)) / t2;
   }
   M3 Vinv = rodrigues_like(w, -0.5, coef);
@@ -246,29 +278,43 @@ MK_DEV Twist se3_log(Q4 q, V3 t) {
 // Blocks of SE3.ljacinv(xi) = [[Ji, B], [0, Ji]] with B = -Ji Q Ji
 // (mink/lie/se3.py:210-249, mink/lie/so3.py:214-226). Returns false when the
 // reference returns exactly I6 (theta^2 below the switch).
+//
+// Q is the reference's sum of products of the skew matrices V = [v]x, W = [w]x,
+//   Q = V/2 + b (WV + VW + WVW) - c (VWW - (VWW)' - 3 WVW) + d (WVWW + WWVW),
+// written out with [a]x[b]x = b a' - (a.b) I, s = v.w, n = v x w:
+//   WV + VW = v w' + w v' - 2 s I,   WVW = -s W,   VWW - (VWW)' = [n x w]x - 2 s W,
+//   WVWW + WWVW = -2 s (w w' - |w|^2 I),
+// i.e. a skew part [v/2 - (b + c) s w - c (n x w)]x plus a symmetric part.
 MK_DEV bool se3_ljacinv_blocks(Twist xi, M3& Ji, M3& B) {
-  double t2 = dot(xi.w, xi.w);
+  const double t2 = dot(xi.w, xi.w);
   if (t2 < MK_LIE_EPS) return false;
-  double th = sqrt(t2);
+  const double th = sqrt(t2);
   double s, c;
-  sincos(th, &s, &c);
+  mk_sincos(th, &s, &c);
   // SO3.ljacinv switches on theta (not theta^2); theta >= 1e-5 here, so closed form.
-  double A = (1.0 / t2) * (1.0 - (th * s / (2.0 * (1.0 - c))));
+  const double it2 = mk_rcp(t2);
+  const double A = it2 * (1.0 - (th * s * mk_rcp(2.0 * (1.0 - c))));
   Ji = rodrigues_like(xi.w, -0.5, A);
-  double Bc = (th - s) / (t2 * th);
-  double Cc = (1.0 - t2 / 2.0 - c) / (t2 * t2);
-  double Dc = (2.0 * th - 3.0 * s + th * c) / (2.0 * t2 * t2 * th);
-  M3 V = skew(xi.v), W = skew(xi.w);
-  M3 VW = mmul(V, W), WV = mtrans(VW);
-  M3 WVW = mmul(WV, W), VWW = mmul(VW, W);
-  M3 WVWW = mmul(WVW, W), WWVW = mmul(W, WVW);
+  const double ith = mk_rcp(th);
+  const double Bc = (th - s) * it2 * ith;
+  const double Cc = (1.0 - 0.5 * t2 - c) * it2 * it2;
+  const double Dc = (2.0 * th - 3.0 * s + th * c) * (0.5 * it2 * it2 * ith);
+  const V3 v = xi.v, w = xi.w;
+  const double sv = dot(v, w);
+  const V3 n = cross(v, w);
+  const V3 k = 0.5 * v - ((Bc + Cc) * sv) * w - Cc * cross(n, w);   // skew part [k]x
+  const double d2 = -2.0 * sv * Dc;
+  const double di = -2.0 * sv * Bc - d2 * t2;                         // multiple of I
   M3 Q;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    int tr = (i % 3) * 3 + i / 3;
-    Q.m[i] = 0.5 * V.m[i] + Bc * (WV.m[i] + VW.m[i] + WVW.m[i]) -
-             Cc * (VWW.m[i] - VWW.m[tr] - 3.0 * WVW.m[i]) + Dc * (WVWW.m[i] + WWVW.m[i]);
-  }
+  Q.m[0] = di + 2.0 * Bc * v.x * w.x + d2 * w.x * w.x;
+  Q.m[4] = di + 2.0 * Bc * v.y * w.y + d2 * w.y * w.y;
+  Q.m[8] = di + 2.0 * Bc * v.z * w.z + d2 * w.z * w.z;
+  const double sxy = Bc * (v.x * w.y + v.y * w.x) + d2 * w.x * w.y;
+  const double sxz = Bc * (v.x * w.z + v.z * w.x) + d2 * w.x * w.z;
+  const double syz = Bc * (v.y * w.z + v.z * w.y) + d2 * w.y * w.z;
+  Q.m[1] = sxy - k.z; Q.m[3] = sxy + k.z;
+  Q.m[2] = sxz + k.y; Q.m[6] = sxz - k.y;
+  Q.m[5] = syz - k.x; Q.m[7] = syz + k.x;
   M3 JQ = mmul(Ji, Q);
   B = mmul(JQ, Ji);
 #pragma unroll

@@ -1,8 +1,8 @@
 // Fused differential-IK kernels: one IK problem per lane, 64 problems per wave.
 //
 // Per problem and per step the kernel does, entirely in registers + one LDS tile:
-//   forward kinematics along the chain to the task frame      (mj_kinematics, K1)
-//   body-frame frame Jacobian on the chain dofs                (mj_jacSite + configuration.py:143-153)
+//   kinematics of the chain to the task frame and the body-frame frame Jacobian on the
+//   chain dofs, in one backward pass     (mj_kinematics, mj_jacSite, configuration.py:143-153)
 //   e = log(T_wb^-1 T_wt), J = -jlog(T_wt^-1 T_wb) J_b          (frame_task.py:95-146)
 //   H = damping I + sum_t (Jw'Jw + mu I), c = -sum_t ew'Jw       (task.py:125-138, solve_ik.py:13-22)
 //   box limits from ConfigurationLimit / VelocityLimit          (configuration_limit.py:98-124,
@@ -257,62 +257,87 @@ MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const do
   return status;
 }
 
-// Chain kinematics of one problem: joint anchors / axes in the world frame, the task
-// frame pose and the frame-task error e = log(T_wb^-1 T_wt).
+// Chain kinematics of one problem: the body-frame Jacobian of the task frame on the
+// chain dofs (rows linear; angular -- what Configuration.get_frame_jacobian returns),
+// the pose of the task frame and the frame-task error e = log(T_wb^-1 T_wt).
 template <int NC>
-struct ChainFK {
-  V3 anchor[NC], axw[NC];
-  V3 ps;
-  M3 Rs;
+struct ChainJac {
+  double J[6][NC];
   Twist e;
 };
 
+// One backward pass from the task frame to the world.  (Q, t) is the pose of the task
+// frame in the frame of the current chain body and R = mat(Q).  A joint with axis a and
+// anchor j (body frame) moves the task frame with the twist (a x (t - j), a) [hinge] or
+// (a, 0) [slide] of that body frame, i.e. the column (R'(a x (t - j)), R'a) in the task
+// frame -- for a z-axis the rows of R directly.  Then the joint displacement and the
+// fixed transform to the parent body are applied on the left.  Mathematically this is
+// mj_kinematics + mj_jacSite + the rotation into the body frame
+// (mink/configuration.py:143-153) without world-frame anchors / axes as intermediates.
 template <int NC>
-MK_DEV void chain_fk(const MkFusedDesc* __restrict__ D, const double (&qc)[NC], Q4 Qt, V3 pt, ChainFK<NC>& fk) {
-  V3 p = v3(0, 0, 0);
-  Q4 Q = Q4{1, 0, 0, 0};
-  M3 R;
+MK_DEV void chain_jac(const MkFusedDesc* __restrict__ D, const double (&qc)[NC], Q4 Qt, V3 pt, ChainJac<NC>& cj) {
+  Q4 Q = Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]};
+  V3 t = v3(D->post_pos[0], D->post_pos[1], D->post_pos[2]);
+  M3 R = q2m(Q);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) R.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
-#pragma unroll
-  for (int k = 0; k < NC; ++k) {
+  for (int k = NC - 1; k >= 0; --k) {
     const MkSeg& s = D->seg[k];
     const int fl = s.flags;
     if (s.type == 0) {  // padding slot
-      fk.axw[k] = v3(0, 0, 0);
-      fk.anchor[k] = v3(0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) cj.J[r][k] = 0.0;
       continue;
     }
-    if (fl & MK_SEG_HAS_PRE) {
-      p = p + mul(R, v3(s.pre_pos[0], s.pre_pos[1], s.pre_pos[2]));
-      Q = qmul(Q, Q4{s.pre_quat[0], s.pre_quat[1], s.pre_quat[2], s.pre_quat[3]});
-      R = q2m(Q);
-    }
-    V3 ax = (fl & MK_SEG_AXIS_Z) ? v3(R.m[2], R.m[5], R.m[8]) : mul(R, v3(s.axis[0], s.axis[1], s.axis[2]));
-    V3 an = (fl & MK_SEG_HAS_JPOS) ? p + mul(R, v3(s.jpos[0], s.jpos[1], s.jpos[2])) : p;
-    fk.axw[k] = ax;
-    fk.anchor[k] = an;
-    double dq = qc[k] - s.qpos0;
+    const V3 a = v3(s.axis[0], s.axis[1], s.axis[2]);
+    const double dq = qc[k] - s.qpos0;
+    bool moved = false;
     if (s.type == MK_SEG_SLIDE) {
-      p = p + dq * ax;
+      const V3 c = (fl & MK_SEG_AXIS_Z) ? v3(R.m[6], R.m[7], R.m[8]) : mulT(R, a);
+      cj.J[0][k] = c.x; cj.J[1][k] = c.y; cj.J[2][k] = c.z;
+      cj.J[3][k] = 0.0; cj.J[4][k] = 0.0; cj.J[5][k] = 0.0;
+      t = t + dq * a;
     } else {
+      const V3 jp = v3(s.jpos[0], s.jpos[1], s.jpos[2]);
+      const V3 d = (fl & MK_SEG_HAS_JPOS) ? t - jp : t;
       double sn, cs;
-      sincos(0.5 * dq, &sn, &cs);
-      Q = qmul(Q, Q4{cs, sn * s.axis[0], sn * s.axis[1], sn * s.axis[2]});
-      if ((fl & MK_SEG_HAS_JPOS) || !(fl & MK_SEG_END_BODY)) {
-        R = q2m(Q);
-        if (fl & MK_SEG_HAS_JPOS) p = an - mul(R, v3(s.jpos[0], s.jpos[1], s.jpos[2]));
+      mk_sincos(0.5 * dq, &sn, &cs);
+      const double c2 = fma(cs, cs, -sn * sn), s2 = 2.0 * sn * cs;   // cos / sin of the full angle
+      V3 dr;
+      if (fl & MK_SEG_AXIS_Z) {
+        cj.J[0][k] = d.x * R.m[3] - d.y * R.m[0];
+        cj.J[1][k] = d.x * R.m[4] - d.y * R.m[1];
+        cj.J[2][k] = d.x * R.m[5] - d.y * R.m[2];
+        cj.J[3][k] = R.m[6]; cj.J[4][k] = R.m[7]; cj.J[5][k] = R.m[8];
+        dr = v3(c2 * d.x - s2 * d.y, s2 * d.x + c2 * d.y, d.z);
+        Q = Q4{cs * Q.w - sn * Q.z, cs * Q.x - sn * Q.y, cs * Q.y + sn * Q.x, cs * Q.z + sn * Q.w};
+      } else {
+        const V3 ad = cross(a, d);
+        const V3 lin = mulT(R, ad), ang = mulT(R, a);
+        cj.J[0][k] = lin.x; cj.J[1][k] = lin.y; cj.J[2][k] = lin.z;
+        cj.J[3][k] = ang.x; cj.J[4][k] = ang.y; cj.J[5][k] = ang.z;
+        dr = c2 * d + s2 * ad + ((1.0 - c2) * dot(a, d)) * a;        // Rodrigues
+        Q = qmul(Q4{cs, sn * a.x, sn * a.y, sn * a.z}, Q);
+      }
+      t = (fl & MK_SEG_HAS_JPOS) ? jp + dr : dr;
+      moved = true;
+    }
+    if (fl & MK_SEG_HAS_PRE) {
+      const V3 pp = v3(s.pre_pos[0], s.pre_pos[1], s.pre_pos[2]);
+      if (fl & MK_SEG_PRE_ROT) {
+        M3 Rp;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rp.m[i] = s.pre_mat[i];
+        t = pp + mul(Rp, t);
+        Q = qmul(Q4{s.pre_quat[0], s.pre_quat[1], s.pre_quat[2], s.pre_quat[3]}, Q);
+        moved = true;
+      } else {
+        t = pp + t;
       }
     }
-    if (fl & MK_SEG_END_BODY) {
-      Q = qnormalize(Q);
-      R = q2m(Q);
-    }
+    if (moved) R = q2m(Q);
   }
-  fk.ps = p + mul(R, v3(D->post_pos[0], D->post_pos[1], D->post_pos[2]));
-  Q4 Qs = qmul(Q, Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]});
-  fk.Rs = q2m(Qs);
-  fk.e = se3_log(qmul(qconj(Qs), Qt), mulT(fk.Rs, pt - fk.ps));
+  // (Q, t, R) is now the pose of the task frame in the world
+  cj.e = se3_log(qmul(qconj(Q), Qt), mulT(R, pt - t));
 }
 
 // Builds and solves the QP of one problem from its chain kinematics. `row` is the
@@ -323,34 +348,31 @@ MK_DEV void chain_fk(const MkFusedDesc* __restrict__ D, const double (&qc)[NC], 
 //                       velocity goes to vrow[dof] when vrow is not null
 template <int NC, bool INTEGRATE>
 MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const double (&qc)[NC],
-                         const ChainFK<NC>& fk, double dt, double inv_dt, double damping, double (&x)[NC],
+                         ChainJac<NC>& cj, double dt, double inv_dt, double damping, double (&x)[NC],
                          double* vrow, uint32_t& act, uint32_t& upper, bool warm, double* hstore,
                          int hstride) {
-  const Twist e = fk.e;
-  const V3 ps = fk.ps;
-  const M3 Rs = fk.Rs;
+  const Twist e = cj.e;
   M3 Ji, Bm;
   const bool full_jlog = se3_ljacinv_blocks(e, Ji, Bm);
   double cost[6];
 #pragma unroll
   for (int r = 0; r < 6; ++r) cost[r] = D->cost[r];
-  double Jw[6][NC];
+  // Jw = diag(cost) (-jlog) J_b, in place (frame_task.py:146, task.py:125-127)
+  double (&Jw)[6][NC] = cj.J;
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
-    const bool hinge = D->seg[k].type == MK_SEG_HINGE;
-    V3 jp = hinge ? cross(fk.axw[k], ps - fk.anchor[k]) : fk.axw[k];
-    V3 bl = mulT(Rs, jp);
-    V3 ba = hinge ? mulT(Rs, fk.axw[k]) : v3(0, 0, 0);
-    V3 tl, ta;
+    const V3 bl = v3(Jw[0][k], Jw[1][k], Jw[2][k]);
+    const V3 ba = v3(Jw[3][k], Jw[4][k], Jw[5][k]);
+    V3 tl = bl, ta = ba;
     if (full_jlog) {
-      tl = neg(mul(Ji, bl) + mul(Bm, ba));
-      ta = neg(mul(Ji, ba));
-    } else {
-      tl = neg(bl);
-      ta = neg(ba);
+      tl = mul(Ji, bl);
+      if (D->seg[k].type == MK_SEG_HINGE) {
+        tl = tl + mul(Bm, ba);
+        ta = mul(Ji, ba);
+      }
     }
-    Jw[0][k] = cost[0] * tl.x; Jw[1][k] = cost[1] * tl.y; Jw[2][k] = cost[2] * tl.z;
-    Jw[3][k] = cost[3] * ta.x; Jw[4][k] = cost[4] * ta.y; Jw[5][k] = cost[5] * ta.z;
+    Jw[0][k] = -cost[0] * tl.x; Jw[1][k] = -cost[1] * tl.y; Jw[2][k] = -cost[2] * tl.z;
+    Jw[3][k] = -cost[3] * ta.x; Jw[4][k] = -cost[4] * ta.y; Jw[5][k] = -cost[5] * ta.z;
   }
   const double g = D->gain;
   double ew[6] = {cost[0] * (-g * e.v.x), cost[1] * (-g * e.v.y), cost[2] * (-g * e.v.z),
@@ -502,10 +524,10 @@ __global__ MK_KERNEL_ATTR void fused_step_kernel(const MkFusedDesc* __restrict__
   double qc[NC], x[NC];
 #pragma unroll
   for (int k = 0; k < NC; ++k) qc[k] = row[D->seg[k].qadr];
-  ChainFK<NC> fk;
-  chain_fk<NC>(D, qc, Qt, pt, fk);
+  ChainJac<NC> cj;
+  chain_jac<NC>(D, qc, Qt, pt, cj);
   uint32_t act = 0u, upper = 0u;
-  int status = solve_problem<NC, false>(D, row, qc, fk, dt, inv_dt, damping, x, nullptr, act, upper, false,
+  int status = solve_problem<NC, false>(D, row, qc, cj, dt, inv_dt, damping, x, nullptr, act, upper, false,
                                         hlds, 64);
 #pragma unroll
   for (int k = 0; k < NC; ++k)
@@ -553,9 +575,9 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
   double* vrow = (valid && v_out) ? v_out + pb * nv : nullptr;
   for (int it = 0; it <= max_iters; ++it) {
     if (!done) {
-      ChainFK<NC> fk;
-      chain_fk<NC>(D, qc, Qt, pt, fk);
-      e = fk.e;
+      ChainJac<NC> cj;
+      chain_jac<NC>(D, qc, Qt, pt, cj);
+      e = cj.e;
       // exit test of the callers' loop, evaluated on the configuration reached by
       // the previous solve (interactive_scripts/teleop_mouse.py:117-121)
       const bool conv = it > 0 && sqrt(dot(e.v, e.v)) <= pos_tol && sqrt(dot(e.w, e.w)) <= ori_tol;
@@ -566,9 +588,9 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
         // tuning build only: forward kinematics + error, no QP build / solve
         int st = 0;
 #pragma unroll
-        for (int k = 0; k < NC; ++k) x[k] = 1e-4 * (fk.e.v.x + fk.e.w.y + fk.anchor[k].x + fk.axw[k].y);
+        for (int k = 0; k < NC; ++k) x[k] = 1e-4 * (cj.e.v.x + cj.e.w.y + cj.J[0][k] + cj.J[4][k]);
 #else
-        int st = solve_problem<NC, true>(D, row, qc, fk, dt, inv_dt, damping, x, vrow, act, upper, it > 0, hlds, 64);
+        int st = solve_problem<NC, true>(D, row, qc, cj, dt, inv_dt, damping, x, vrow, act, upper, it > 0, hlds, 64);
 #endif
         status = max(status, st);
         iters = it + 1;

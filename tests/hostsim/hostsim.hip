@@ -21,8 +21,8 @@ int run_step(const MkFusedDesc& D, const double* q, const double* targets, int s
     const double* tg = targets + (size_t)b * stride + D.target_off;
     double qc[NC], x[NC];
     for (int k = 0; k < NC; ++k) qc[k] = row[D.seg[k].qadr];
-    ChainFK<NC> fk;
-    chain_fk<NC>(&D, qc, Q4{tg[0], tg[1], tg[2], tg[3]}, v3(tg[4], tg[5], tg[6]), fk);
+    ChainJac<NC> fk;
+    chain_jac<NC>(&D, qc, Q4{tg[0], tg[1], tg[2], tg[3]}, v3(tg[4], tg[5], tg[6]), fk);
     uint32_t act = 0u, upper = 0u;
     status[b] = solve_problem<NC, false>(&D, row.data(), qc, fk, dt, 1.0 / dt, damping, x, nullptr, act, upper, false, hbuf, 1);
     for (int k = 0; k < NC; ++k)
@@ -50,8 +50,8 @@ int run_iterate(const MkFusedDesc& D, double* q, const double* targets, int stri
     int status = 0, iters = 0;
     uint32_t act = 0u, upper = 0u;
     for (int it = 0; it <= max_iters; ++it) {
-      ChainFK<NC> fk;
-      chain_fk<NC>(&D, qc, Qt, pt, fk);
+      ChainJac<NC> fk;
+      chain_jac<NC>(&D, qc, Qt, pt, fk);
       e = fk.e;
       const bool conv = it > 0 && sqrt(dot(e.v, e.v)) <= pos_tol && sqrt(dot(e.w, e.w)) <= ori_tol;
       if (conv || it == max_iters) break;
