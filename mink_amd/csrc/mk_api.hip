@@ -210,7 +210,11 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
   if (frame_body_and_local(m, ft.frame_type, ft.frame_id, &body, lpos, lquat) != MK_OK) { why = g_last_error; return false; }
   std::vector<int> path;
   for (int b = body; b != 0; b = m.body_parentid[b]) path.insert(path.begin(), b);
-  double ppos[3] = {0, 0, 0}, pquat[4] = {1, 0, 0, 0};
+  // Walk the chain and bring every joint to canonical form.  A joint with unit axis a and
+  // anchor j in its body frame is F Jz(q - qpos0) F^-1 with F = (translation j, rotation
+  // taking z to a) and Jz the motion about / along z; F and Jz(-qpos0) go into the fixed
+  // transform in front of the joint, F^-1 into the one behind it (`carry`).
+  double ppos[3] = {0, 0, 0}, pquat[4] = {1, 0, 0, 0};   // fixed transform since the previous joint
   int nc = 0;
   for (int b : path) {
     if (m.body_mocapid[b] >= 0) { why = "frame attached to a mocap body"; return false; }
@@ -220,39 +224,40 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
       const int jt = m.jnt_type[j];
       if (jt != MK_JNT_HINGE && jt != MK_JNT_SLIDE) { why = "free/ball joint on the task chain"; return false; }
       if (nc >= MK_MAX_CHAIN) { why = "task chain longer than the fused kernels support"; return false; }
-      MkSeg& s = D.seg[nc];
-      s.type = jt;
-      s.qadr = m.jnt_qposadr[j];
-      s.dof = m.jnt_dofadr[j];
-      s.qpos0 = m.qpos0[s.qadr];
-      memcpy(s.jpos, &m.jnt_pos[3 * j], sizeof(s.jpos));
-      memcpy(s.axis, &m.jnt_axis[3 * j], sizeof(s.axis));
-      {  // MuJoCo stores unit axes; make sure of it for descriptors that come from elsewhere
-        const double n = sqrt(s.axis[0] * s.axis[0] + s.axis[1] * s.axis[1] + s.axis[2] * s.axis[2]);
-        if (!(n > MK_MINVAL)) { why = "zero joint axis on the task chain"; return false; }
-        for (double& c : s.axis) c /= n;
+      double a[3] = {m.jnt_axis[3 * j], m.jnt_axis[3 * j + 1], m.jnt_axis[3 * j + 2]};
+      const double an = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+      if (!(an > MK_MINVAL)) { why = "zero joint axis on the task chain"; return false; }
+      for (double& c : a) c /= an;
+      // F: shortest rotation taking z to a (half-turn about x when a = -z), anchored at j for hinges
+      double fq[4] = {1.0 + a[2], -a[1], a[0], 0.0};
+      if (1.0 + a[2] < 1e-12) { fq[0] = 0.0; fq[1] = 1.0; fq[2] = 0.0; }
+      hq_normalize(fq);
+      const double zero3[3] = {0, 0, 0};
+      const double* fp = (jt == MK_JNT_HINGE) ? &m.jnt_pos[3 * j] : zero3;
+      compose(ppos, pquat, fp, fq);
+      const int qadr = m.jnt_qposadr[j];
+      const double q0 = m.qpos0[qadr];
+      if (q0 != 0.0) {  // Jz(-qpos0)
+        const double zq[4] = {std::cos(-0.5 * q0), 0.0, 0.0, std::sin(-0.5 * q0)};
+        const double zp[3] = {0.0, 0.0, -q0};
+        const double id[4] = {1, 0, 0, 0};
+        if (jt == MK_JNT_HINGE) compose(ppos, pquat, zero3, zq); else compose(ppos, pquat, zp, id);
       }
-      s.flags = 0;
-      s.pre_mat[0] = s.pre_mat[4] = s.pre_mat[8] = 1.0;
-      if (j == ja) {
-        s.flags |= MK_SEG_HAS_PRE;
-        memcpy(s.pre_pos, ppos, sizeof(ppos));
-        memcpy(s.pre_quat, pquat, sizeof(pquat));
-        if (!(pquat[0] == 1.0 && pquat[1] == 0.0 && pquat[2] == 0.0 && pquat[3] == 0.0)) {
-          s.flags |= MK_SEG_PRE_ROT;
-          const M3 Rp = q2m(Q4{pquat[0], pquat[1], pquat[2], pquat[3]});
-          memcpy(s.pre_mat, Rp.m, sizeof(s.pre_mat));
-        }
-        ppos[0] = ppos[1] = ppos[2] = 0.0;
-        pquat[0] = 1.0; pquat[1] = pquat[2] = pquat[3] = 0.0;
-      } else {
-        s.pre_quat[0] = 1.0;
-      }
-      if (j == ja + jn - 1) s.flags |= MK_SEG_END_BODY;
-      if (s.jpos[0] != 0.0 || s.jpos[1] != 0.0 || s.jpos[2] != 0.0) s.flags |= MK_SEG_HAS_JPOS;
-      if (s.axis[0] == 0.0 && s.axis[1] == 0.0 && s.axis[2] == 1.0) s.flags |= MK_SEG_AXIS_Z;
-      D.dof[s.dof].slot = nc;
+      MkSegC& sc = D.segc[nc];
+      memcpy(sc.pq, pquat, sizeof(pquat));
+      memcpy(sc.pp, ppos, sizeof(ppos));
+      sc.hinge = (jt == MK_JNT_HINGE) ? 1.0 : 0.0;
+      sc.slide = 1.0 - sc.hinge;
+      D.seg_qadr[nc] = qadr;
+      D.seg_dof[nc] = m.jnt_dofadr[j];
+      D.dof[m.jnt_dofadr[j]].slot = nc;
       ++nc;
+      // carry = F^-1: rotation conj(fq), translation -R(conj(fq)) fp
+      const double fqi[4] = {fq[0], -fq[1], -fq[2], -fq[3]};
+      double r[3];
+      hq_rotate(fqi, fp, r);
+      ppos[0] = -r[0]; ppos[1] = -r[1]; ppos[2] = -r[2];
+      memcpy(pquat, fqi, sizeof(fqi));
     }
   }
   if (nc == 0) { why = "task frame has no moving joints"; return false; }
@@ -263,10 +268,10 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
   for (int s : kFusedSizes)
     if (s >= nc) { nk = s; break; }
   if (nk < 0) { why = "task chain longer than the fused kernels support"; return false; }
-  for (int k = nc; k < nk; ++k) {  // padding slots: no joint, unit Hessian entry
-    D.seg[k].type = 0;
-    D.seg[k].dof = -1;
-    D.seg[k].pre_quat[0] = 1.0;
+  for (int k = nc; k < nk; ++k) {  // padding slots: identity transform, no motion
+    D.segc[k].pq[0] = 1.0;
+    D.seg_qadr[k] = 0;
+    D.seg_dof[k] = -1;
   }
   D.nc = nc;
   *nc_kernel = nk;
@@ -346,8 +351,14 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
   for (int t = 0; t < D.nposture; ++t)
     if (D.posture[t].lm > 0.0) D.any_posture_lm = 1;
   for (int k = 0; k < nk; ++k) {
-    if (D.seg[k].dof < 0) { memset(&D.sdof[k], 0, sizeof(MkDofC)); D.sdof[k].dof = -1; continue; }
-    if (!pack(D.seg[k].dof, D.sdof[k])) { why = "several configuration limits on one dof"; return false; }
+    if (D.seg_dof[k] < 0) {  // padding slot: decoupled unit entry with infinite bounds -> solution 0
+      MkDofC& c = D.sdof[k];
+      c.A = c.B = 0.0; c.W = 1.0;
+      c.lower = -INFINITY; c.upper = INFINITY; c.gain = 1.0; c.vmax = INFINITY;
+      c.qadr = 0; c.dof = -1;
+      continue;
+    }
+    if (!pack(D.seg_dof[k], D.sdof[k])) { why = "several configuration limits on one dof"; return false; }
   }
   for (int i = 0; i < m.nv; ++i) {
     if (D.dof[i].slot >= 0 || D.dof[i].kind != MK_DOF_SCALAR) continue;

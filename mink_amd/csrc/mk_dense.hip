@@ -523,13 +523,9 @@ __global__ __launch_bounds__(64) void dense_kernel(MkDevModel m, const MkDensePr
       Twist arg = sign < 0 ? e : Twist{neg(e.v), neg(e.w)};
       M3 Ji, Bm;
       V3 jl, ja;
-      if (se3_ljacinv_blocks(arg, Ji, Bm)) {
-        jl = mul(Ji, dl) + mul(Bm, da);
-        ja = mul(Ji, da);
-      } else {
-        jl = dl;
-        ja = da;
-      }
+      se3_ljacinv_blocks(arg, Ji, Bm);   // I, 0 below the small-angle switch
+      jl = mul(Ji, dl) + mul(Bm, da);
+      ja = mul(Ji, da);
       Jraw[0] = sign * jl.x; Jraw[1] = sign * jl.y; Jraw[2] = sign * jl.z;
       Jraw[3] = sign * ja.x; Jraw[4] = sign * ja.y; Jraw[5] = sign * ja.z;
       eraw[0] = e.v.x; eraw[1] = e.v.y; eraw[2] = e.v.z; eraw[3] = e.w.x; eraw[4] = e.w.y; eraw[5] = e.w.z;

@@ -23,24 +23,22 @@ constexpr double MK_LIE_EPS = 1e-10;  // mink/lie/utils.py:4-8, float64
 constexpr double MK_MINVAL = 1e-15;   // MuJoCo mjMINVAL
 constexpr double MK_PI = 3.14159265358979323846;
 
-enum { MK_SEG_SLIDE = 2, MK_SEG_HINGE = 3 };
-enum { MK_SEG_HAS_PRE = 1, MK_SEG_END_BODY = 2, MK_SEG_HAS_JPOS = 4, MK_SEG_AXIS_Z = 8, MK_SEG_PRE_ROT = 16 };
 enum { MK_TERM_CFG = 0, MK_TERM_VEL = 1 };
 enum { MK_DOF_SCALAR = 0, MK_DOF_FREE_LIN = 1, MK_DOF_FREE_ROT = 2, MK_DOF_BALL = 3 };
 
-// One 1-dof joint of the kinematic chain from the world to the task frame,
-// preceded by the fixed transform that leads to the joint's body.
-struct MkSeg {
-  double pre_pos[3];
-  double pre_quat[4];
-  double pre_mat[9];  // rotation matrix of pre_quat (row-major); read when MK_SEG_PRE_ROT is set
-  double jpos[3];   // joint anchor in the body frame
-  double axis[3];   // joint axis in the body frame
-  double qpos0;
-  int32_t type;     // MK_SEG_SLIDE / MK_SEG_HINGE
-  int32_t flags;
-  int32_t qadr;
-  int32_t dof;
+// One 1-dof joint of the kinematic chain from the world to the task frame in canonical
+// form: the joint moves about / along the z axis through the origin of its own frame
+// (any axis and anchor are brought to this form on the host by a change of the fixed
+// frames either side of the joint, like Denavit-Hartenberg frames), its qpos0 offset is
+// folded into the fixed transform (pq, pp) that leads from the previous joint frame to
+// this one.  (hinge, slide) is (1, 0) for a hinge, (0, 1) for a slide and (0, 0) for a
+// padding slot, which then contributes a zero Jacobian column and no motion.
+struct MkSegC {
+  double pq[4];
+  double pp[3];
+  double hinge;
+  double slide;
+  double pad;
 };
 
 struct MkBoundTerm {
@@ -76,8 +74,10 @@ struct MkFusedDesc {
   int32_t nq, nv, nc, nposture;
   int32_t nfree, target_off, pad0, pad1;
   int32_t free_qadr[8];        // qpos address of each free joint (7 values)
-  MkSeg seg[MK_MAX_CHAIN];
-  double post_pos[3], post_quat[4];   // last chain body -> task frame
+  MkSegC segc[MK_MAX_CHAIN];
+  int32_t seg_qadr[MK_MAX_CHAIN];     // qpos address of each chain slot (0 for padding slots)
+  int32_t seg_dof[MK_MAX_CHAIN];      // dof of each chain slot (-1 for padding slots)
+  double post_pos[3], post_quat[4];   // last joint frame -> task frame
   double cost[6], gain, lm;           // frame task
   MkPosture posture[MK_MAX_POSTURE];   // only read when a posture task has lm_damping > 0
   MkDof dof[MK_MAX_NV];
@@ -175,6 +175,13 @@ MK_DEV Q4 qmul(Q4 a, Q4 b) {
             a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
 }
 MK_DEV Q4 qconj(Q4 a) { return Q4{a.w, -a.x, -a.y, -a.z}; }
+// Rotation of v by the unit quaternion q: v + 2 u x (u x v + w v).
+MK_DEV V3 qrot(Q4 q, V3 v) {
+  const V3 u = V3{q.x, q.y, q.z};
+  const V3 c = cross(u, v) + q.w * v;
+  const V3 d = cross(u, c);
+  return V3{fma(2.0, d.x, v.x), fma(2.0, d.y, v.y), fma(2.0, d.z, v.z)};
+}
 
 // mju_normalize4: a vanishing quaternion maps to identity.
 MK_DEV Q4 qnormalize(Q4 q) {
@@ -239,20 +246,18 @@ MK_DEV M3 mtrans(const M3& a) {
   return r;
 }
 
-// SO3.log of a unit quaternion (mink/lie/so3.py:176-191), safe for w < 0.
+// SO3.log of a unit quaternion (mink/lie/so3.py:176-191), safe for w < 0.  The three
+// cases of the reference (small angle, |w| ~ 0, general) are all evaluated and selected,
+// so that the code stays straight-line.
 MK_DEV V3 so3_log(Q4 q) {
-  double n2 = q.x * q.x + q.y * q.y + q.z * q.z;
-  double f;
-  if (n2 < MK_LIE_EPS) {
-    f = 2.0 / q.w - 2.0 / 3.0 * n2 / (q.w * q.w * q.w);
-  } else {
-    double n = sqrt(n2);
-    if (fabs(q.w) < MK_LIE_EPS) {
-      f = (q.w > 0.0 ? 1.0 : -1.0) * MK_PI / n;
-    } else {
-      f = 2.0 * atan2(q.w < 0 ? -n : n, fabs(q.w)) / n;
-    }
-  }
+  const double n2 = q.x * q.x + q.y * q.y + q.z * q.z;
+  const double iw = mk_rcp(q.w);
+  const double f_small = 2.0 * iw - 2.0 / 3.0 * n2 * (iw * iw * iw);
+  const double n2s = fmax(n2, 1e-300);
+  const double rn = mk_rsqrt(n2s), n = n2s * rn;
+  const double f_pi = (q.w > 0.0 ? MK_PI : -MK_PI) * rn;
+  const double f_gen = 2.0 * atan2(q.w < 0 ? -n : n, fabs(q.w)) * rn;
+  const double f = (n2 < MK_LIE_EPS) ? f_small : ((fabs(q.w) < MK_LIE_EPS) ? f_pi : f_gen);
   return V3{f * q.x, f * q.y, f * q.z};
 }
 
@@ -260,24 +265,21 @@ struct Twist { V3 v, w; };
 
 // SE3.log (mink/lie/se3.py:159-185) of the transform (q, t).
 MK_DEV Twist se3_log(Q4 q, V3 t) {
-  V3 w = so3_log(q);
-  double t2 = dot(w, w);
-  double coef;
-  if (t2 < MK_LIE_EPS) {
-    coef = 1.0 / 12.0;
-  } else {
-    double th = sqrt(t2), h = 0.5 * th;
-    double s, c;
-    mk_sincos(h, &s, &c);
-    coef = (1.0 - th * c / (2.0 * s)) / t2;
-  }
+  const V3 w = so3_log(q);
+  const double t2 = dot(w, w);
+  const double t2s = fmax(t2, 1e-300);
+  const double rth = mk_rsqrt(t2s), th = t2s * rth;
+  double s, c;
+  mk_sincos(0.5 * th, &s, &c);
+  const double coef_gen = (1.0 - th * c * mk_rcp(2.0 * s)) * (rth * rth);
+  const double coef = (t2 < MK_LIE_EPS) ? 1.0 / 12.0 : coef_gen;
   M3 Vinv = rodrigues_like(w, -0.5, coef);
   return Twist{mul(Vinv, t), w};
 }
 
 // Blocks of SE3.ljacinv(xi) = [[Ji, B], [0, Ji]] with B = -Ji Q Ji
-// (mink/lie/se3.py:210-249, mink/lie/so3.py:214-226). Returns false when the
-// reference returns exactly I6 (theta^2 below the switch).
+// (mink/lie/se3.py:210-249, mink/lie/so3.py:214-226); Ji = I, B = 0 when the reference
+// returns exactly I6 (theta^2 below the switch).
 //
 // Q is the reference's sum of products of the skew matrices V = [v]x, W = [w]x,
 //   Q = V/2 + b (WV + VW + WVW) - c (VWW - (VWW)' - 3 WVW) + d (WVWW + WWVW),
@@ -285,17 +287,21 @@ MK_DEV Twist se3_log(Q4 q, V3 t) {
 //   WV + VW = v w' + w v' - 2 s I,   WVW = -s W,   VWW - (VWW)' = [n x w]x - 2 s W,
 //   WVWW + WWVW = -2 s (w w' - |w|^2 I),
 // i.e. a skew part [v/2 - (b + c) s w - c (n x w)]x plus a symmetric part.
-MK_DEV bool se3_ljacinv_blocks(Twist xi, M3& Ji, M3& B) {
+MK_DEV void se3_ljacinv_blocks(Twist xi, M3& Ji, M3& B) {
   const double t2 = dot(xi.w, xi.w);
-  if (t2 < MK_LIE_EPS) return false;
-  const double th = sqrt(t2);
+  if (t2 < MK_LIE_EPS) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { Ji.m[i] = (i % 4 == 0) ? 1.0 : 0.0; B.m[i] = 0.0; }
+    return;
+  }
+  const double rth = mk_rsqrt(t2), th = t2 * rth;
   double s, c;
   mk_sincos(th, &s, &c);
   // SO3.ljacinv switches on theta (not theta^2); theta >= 1e-5 here, so closed form.
-  const double it2 = mk_rcp(t2);
+  const double it2 = rth * rth;
   const double A = it2 * (1.0 - (th * s * mk_rcp(2.0 * (1.0 - c))));
   Ji = rodrigues_like(xi.w, -0.5, A);
-  const double ith = mk_rcp(th);
+  const double ith = rth;
   const double Bc = (th - s) * it2 * ith;
   const double Cc = (1.0 - 0.5 * t2 - c) * it2 * it2;
   const double Dc = (2.0 * th - 3.0 * s + th * c) * (0.5 * it2 * it2 * ith);
@@ -319,5 +325,4 @@ MK_DEV bool se3_ljacinv_blocks(Twist xi, M3& Ji, M3& B) {
   B = mmul(JQ, Ji);
 #pragma unroll
   for (int i = 0; i < 9; ++i) B.m[i] = -B.m[i];
-  return true;
 }

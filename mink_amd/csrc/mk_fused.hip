@@ -267,13 +267,15 @@ struct ChainJac {
 };
 
 // One backward pass from the task frame to the world.  (Q, t) is the pose of the task
-// frame in the frame of the current chain body and R = mat(Q).  A joint with axis a and
-// anchor j (body frame) moves the task frame with the twist (a x (t - j), a) [hinge] or
-// (a, 0) [slide] of that body frame, i.e. the column (R'(a x (t - j)), R'a) in the task
-// frame -- for a z-axis the rows of R directly.  Then the joint displacement and the
-// fixed transform to the parent body are applied on the left.  Mathematically this is
-// mj_kinematics + mj_jacSite + the rotation into the body frame
-// (mink/configuration.py:143-153) without world-frame anchors / axes as intermediates.
+// frame in the current joint frame and R = mat(Q).  Joints are in canonical form (about
+// / along the z axis of their own frame, see MkSegC), so a hinge moves the task frame
+// with the twist (z x t, z) and a slide with (z, 0) of that frame; expressed in the task
+// frame these are (t.x R[1] - t.y R[0], R[2]) and (R[2], 0) in terms of the rows of R.
+// Then the joint displacement and the fixed transform to the previous joint frame are
+// applied on the left.  This is mj_kinematics + mj_jacSite + the rotation into the body
+// frame (mink/configuration.py:143-153) without world-frame anchors / axes as
+// intermediates.  Hinges, slides and padding slots share one instruction stream (the
+// `hinge` factor of the slot selects), so the pass is straight-line code.
 template <int NC>
 MK_DEV void chain_jac(const MkFusedDesc* __restrict__ D, const double (&qc)[NC], Q4 Qt, V3 pt, ChainJac<NC>& cj) {
   Q4 Q = Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]};
@@ -281,63 +283,46 @@ MK_DEV void chain_jac(const MkFusedDesc* __restrict__ D, const double (&qc)[NC],
   M3 R = q2m(Q);
 #pragma unroll
   for (int k = NC - 1; k >= 0; --k) {
-    const MkSeg& s = D->seg[k];
-    const int fl = s.flags;
-    if (s.type == 0) {  // padding slot
-#pragma unroll
-      for (int r = 0; r < 6; ++r) cj.J[r][k] = 0.0;
-      continue;
-    }
-    const V3 a = v3(s.axis[0], s.axis[1], s.axis[2]);
-    const double dq = qc[k] - s.qpos0;
-    bool moved = false;
-    if (s.type == MK_SEG_SLIDE) {
-      const V3 c = (fl & MK_SEG_AXIS_Z) ? v3(R.m[6], R.m[7], R.m[8]) : mulT(R, a);
-      cj.J[0][k] = c.x; cj.J[1][k] = c.y; cj.J[2][k] = c.z;
-      cj.J[3][k] = 0.0; cj.J[4][k] = 0.0; cj.J[5][k] = 0.0;
-      t = t + dq * a;
-    } else {
-      const V3 jp = v3(s.jpos[0], s.jpos[1], s.jpos[2]);
-      const V3 d = (fl & MK_SEG_HAS_JPOS) ? t - jp : t;
-      double sn, cs;
-      mk_sincos(0.5 * dq, &sn, &cs);
-      const double c2 = fma(cs, cs, -sn * sn), s2 = 2.0 * sn * cs;   // cos / sin of the full angle
-      V3 dr;
-      if (fl & MK_SEG_AXIS_Z) {
-        cj.J[0][k] = d.x * R.m[3] - d.y * R.m[0];
-        cj.J[1][k] = d.x * R.m[4] - d.y * R.m[1];
-        cj.J[2][k] = d.x * R.m[5] - d.y * R.m[2];
-        cj.J[3][k] = R.m[6]; cj.J[4][k] = R.m[7]; cj.J[5][k] = R.m[8];
-        dr = v3(c2 * d.x - s2 * d.y, s2 * d.x + c2 * d.y, d.z);
-        Q = Q4{cs * Q.w - sn * Q.z, cs * Q.x - sn * Q.y, cs * Q.y + sn * Q.x, cs * Q.z + sn * Q.w};
-      } else {
-        const V3 ad = cross(a, d);
-        const V3 lin = mulT(R, ad), ang = mulT(R, a);
-        cj.J[0][k] = lin.x; cj.J[1][k] = lin.y; cj.J[2][k] = lin.z;
-        cj.J[3][k] = ang.x; cj.J[4][k] = ang.y; cj.J[5][k] = ang.z;
-        dr = c2 * d + s2 * ad + ((1.0 - c2) * dot(a, d)) * a;        // Rodrigues
-        Q = qmul(Q4{cs, sn * a.x, sn * a.y, sn * a.z}, Q);
-      }
-      t = (fl & MK_SEG_HAS_JPOS) ? jp + dr : dr;
-      moved = true;
-    }
-    if (fl & MK_SEG_HAS_PRE) {
-      const V3 pp = v3(s.pre_pos[0], s.pre_pos[1], s.pre_pos[2]);
-      if (fl & MK_SEG_PRE_ROT) {
-        M3 Rp;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Rp.m[i] = s.pre_mat[i];
-        t = pp + mul(Rp, t);
-        Q = qmul(Q4{s.pre_quat[0], s.pre_quat[1], s.pre_quat[2], s.pre_quat[3]}, Q);
-        moved = true;
-      } else {
-        t = pp + t;
-      }
-    }
-    if (moved) R = q2m(Q);
+    const MkSegC& s = D->segc[k];
+    const double h = s.hinge;
+    const double th = h * qc[k];       // hinge angle (0 for a slide)
+    double sn, cs;
+    mk_sincos(0.5 * th, &sn, &cs);
+    const double hx = h * t.x, hy = h * t.y, sl = s.slide;
+    cj.J[0][k] = fma(hx, R.m[3], fma(-hy, R.m[0], sl * R.m[6]));
+    cj.J[1][k] = fma(hx, R.m[4], fma(-hy, R.m[1], sl * R.m[7]));
+    cj.J[2][k] = fma(hx, R.m[5], fma(-hy, R.m[2], sl * R.m[8]));
+    cj.J[3][k] = h * R.m[6];
+    cj.J[4][k] = h * R.m[7];
+    cj.J[5][k] = h * R.m[8];
+    t.z = fma(sl, qc[k], t.z);         // slide displacement
+    // fixed transform to the previous joint frame times the joint rotation about z
+    const Q4 Qs = Q4{s.pq[0] * cs - s.pq[3] * sn, s.pq[1] * cs + s.pq[2] * sn, s.pq[2] * cs - s.pq[1] * sn,
+                     s.pq[3] * cs + s.pq[0] * sn};
+    t = qrot(Qs, t) + v3(s.pp[0], s.pp[1], s.pp[2]);
+    Q = qmul(Qs, Q);
+    R = q2m(Q);
   }
   // (Q, t, R) is now the pose of the task frame in the world
   cj.e = se3_log(qmul(qconj(Q), Qt), mulT(R, pt - t));
+}
+
+template <int NC>
+MK_DEV void store_chain_q(const MkFusedDesc* __restrict__ D, double* row, const double (&qc)[NC]) {
+#pragma unroll
+  for (int k = 0; k < NC; ++k)
+    if (D->seg_dof[k] >= 0) row[D->seg_qadr[k]] = qc[k];
+}
+
+// Chain coordinates of one problem from its q row; padding slots read as 0 so that they
+// neither rotate nor translate.
+template <int NC>
+MK_DEV void load_chain_q(const MkFusedDesc* __restrict__ D, const double* row, double (&qc)[NC]) {
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const double v = row[D->seg_qadr[k]];
+    qc[k] = (D->seg_dof[k] >= 0) ? v : 0.0;
+  }
 }
 
 // Builds and solves the QP of one problem from its chain kinematics. `row` is the
@@ -353,7 +338,7 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
                          int hstride) {
   const Twist e = cj.e;
   M3 Ji, Bm;
-  const bool full_jlog = se3_ljacinv_blocks(e, Ji, Bm);
+  se3_ljacinv_blocks(e, Ji, Bm);
   double cost[6];
 #pragma unroll
   for (int r = 0; r < 6; ++r) cost[r] = D->cost[r];
@@ -363,14 +348,8 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
   for (int k = 0; k < NC; ++k) {
     const V3 bl = v3(Jw[0][k], Jw[1][k], Jw[2][k]);
     const V3 ba = v3(Jw[3][k], Jw[4][k], Jw[5][k]);
-    V3 tl = bl, ta = ba;
-    if (full_jlog) {
-      tl = mul(Ji, bl);
-      if (D->seg[k].type == MK_SEG_HINGE) {
-        tl = tl + mul(Bm, ba);
-        ta = mul(Ji, ba);
-      }
-    }
+    const V3 tl = mul(Ji, bl) + mul(Bm, ba);
+    const V3 ta = mul(Ji, ba);
     Jw[0][k] = -cost[0] * tl.x; Jw[1][k] = -cost[1] * tl.y; Jw[2][k] = -cost[2] * tl.z;
     Jw[3][k] = -cost[3] * ta.x; Jw[4][k] = -cost[4] * ta.y; Jw[5][k] = -cost[5] * ta.z;
   }
@@ -412,14 +391,8 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
   }
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
+    // padding slots carry W = 1, A = B = 0 and infinite bounds: a decoupled entry with solution 0
     const MkDofC& dc = D->sdof[k];
-    if (dc.dof < 0) {  // padding slot: decoupled unit entry, solution 0
-      H[tri(k, k)] = 1.0;
-      c[k] = 0.0;
-      lo[k] = -INFINITY;
-      hi[k] = INFINITY;
-      continue;
-    }
     H[tri(k, k)] += diag + dc.W;
     c[k] += dc.B * qc[k] - dc.A;
     const double vb = dt * dc.vmax;
@@ -448,8 +421,11 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
 #endif
 
   // ---- dofs outside the chain: diagonal Hessian, box limits -> clamp ----
-  for (int d = 0; d < D->nd; ++d) {
-    const MkDofC& dc = D->ddof[d];
+  // (the constants of the next dof are fetched while the current one is computed)
+  const int nd = D->nd;
+  MkDofC dc = D->ddof[0];
+  for (int d = 0; d < nd; ++d) {
+    const MkDofC nx = D->ddof[d + 1 < MK_MAX_NV ? d + 1 : d];
     const double qi = row[dc.qadr];
     const double vb = dt * dc.vmax;
     const double h = fmin(dc.gain * (dc.upper - qi), vb);
@@ -463,6 +439,7 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
     } else {
       row[dc.dof] = vi;
     }
+    dc = nx;
   }
   // free-joint dofs: zero Jacobian columns and zeroed posture rows -> v = 0
   for (int f = 0; f < D->nfree; ++f) {
@@ -522,8 +499,7 @@ __global__ MK_KERNEL_ATTR void fused_step_kernel(const MkFusedDesc* __restrict__
   Q4 Qt = Q4{tg[0], tg[1], tg[2], tg[3]};
   V3 pt = v3(tg[4], tg[5], tg[6]);
   double qc[NC], x[NC];
-#pragma unroll
-  for (int k = 0; k < NC; ++k) qc[k] = row[D->seg[k].qadr];
+  load_chain_q<NC>(D, row, qc);
   ChainJac<NC> cj;
   chain_jac<NC>(D, qc, Qt, pt, cj);
   uint32_t act = 0u, upper = 0u;
@@ -531,7 +507,7 @@ __global__ MK_KERNEL_ATTR void fused_step_kernel(const MkFusedDesc* __restrict__
                                         hlds, 64);
 #pragma unroll
   for (int k = 0; k < NC; ++k)
-    if (D->seg[k].dof >= 0) row[D->seg[k].dof] = x[k] * inv_dt;
+    if (D->seg_dof[k] >= 0) row[D->seg_dof[k]] = x[k] * inv_dt;
   if (valid) status_out[pb] = status;
   __syncthreads();
   tile_copy<false>(tile, stride, v_out + base * nv, rows, nv);
@@ -566,8 +542,10 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
   Q4 Qt = Q4{tg[0], tg[1], tg[2], tg[3]};
   V3 pt = v3(tg[4], tg[5], tg[6]);
   double qc[NC], x[NC];
+  load_chain_q<NC>(D, row, qc);
 #pragma unroll
-  for (int k = 0; k < NC; ++k) { qc[k] = row[D->seg[k].qadr]; x[k] = 0.0; }
+  for (int k = 0; k < NC; ++k) x[k] = 0.0;
+  const bool sync_rows = D->any_posture_lm != 0;   // only that path reads chain q from the rows
   Twist e = Twist{v3(0, 0, 0), v3(0, 0, 0)};
   int status = 0, iters = 0;
   bool done = false;
@@ -599,16 +577,17 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
           double vk = x[k] * inv_dt;
           x[k] = vk;
           qc[k] = qc[k] + dt * vk;
-          if (D->seg[k].dof >= 0) row[D->seg[k].qadr] = qc[k];
         }
+        if (sync_rows) store_chain_q<NC>(D, row, qc);
       }
     }
     if (mk_wave_none(!done)) break;
   }
+  store_chain_q<NC>(D, row, qc);
   if (vrow) {
 #pragma unroll
     for (int k = 0; k < NC; ++k)
-      if (D->seg[k].dof >= 0) vrow[D->seg[k].dof] = x[k];
+      if (D->seg_dof[k] >= 0) vrow[D->seg_dof[k]] = x[k];
   }
   if (valid) {
     status_out[pb] = status;

@@ -11,6 +11,10 @@
 
 namespace {
 
+// optional per-(problem, iteration) record of the QP work: phase-1 rounds, phase-2 steps
+int32_t* g_trace = nullptr;
+int g_trace_iters = 0;
+
 template <int NC>
 int run_step(const MkFusedDesc& D, const double* q, const double* targets, int stride, double dt, double damping,
              int B, double* v, int32_t* status) {
@@ -20,13 +24,13 @@ int run_step(const MkFusedDesc& D, const double* q, const double* targets, int s
     memcpy(row.data(), q + (size_t)b * D.nq, D.nq * sizeof(double));
     const double* tg = targets + (size_t)b * stride + D.target_off;
     double qc[NC], x[NC];
-    for (int k = 0; k < NC; ++k) qc[k] = row[D.seg[k].qadr];
+    load_chain_q<NC>(&D, row.data(), qc);
     ChainJac<NC> fk;
     chain_jac<NC>(&D, qc, Q4{tg[0], tg[1], tg[2], tg[3]}, v3(tg[4], tg[5], tg[6]), fk);
     uint32_t act = 0u, upper = 0u;
     status[b] = solve_problem<NC, false>(&D, row.data(), qc, fk, dt, 1.0 / dt, damping, x, nullptr, act, upper, false, hbuf, 1);
     for (int k = 0; k < NC; ++k)
-      if (D.seg[k].dof >= 0) row[D.seg[k].dof] = x[k] * (1.0 / dt);
+      if (D.seg_dof[k] >= 0) row[D.seg_dof[k]] = x[k] * (1.0 / dt);
     memcpy(v + (size_t)b * D.nv, row.data(), D.nv * sizeof(double));
   }
   return 0;
@@ -44,7 +48,8 @@ int run_iterate(const MkFusedDesc& D, double* q, const double* targets, int stri
     Q4 Qt{tg[0], tg[1], tg[2], tg[3]};
     V3 pt = v3(tg[4], tg[5], tg[6]);
     double qc[NC], x[NC];
-    for (int k = 0; k < NC; ++k) { qc[k] = row[D.seg[k].qadr]; x[k] = 0.0; }
+    load_chain_q<NC>(&D, row.data(), qc);
+    for (int k = 0; k < NC; ++k) x[k] = 0.0;
     double* vrow = v ? v + (size_t)b * D.nv : nullptr;
     Twist e{};
     int status = 0, iters = 0;
@@ -55,19 +60,28 @@ int run_iterate(const MkFusedDesc& D, double* q, const double* targets, int stri
       e = fk.e;
       const bool conv = it > 0 && sqrt(dot(e.v, e.v)) <= pos_tol && sqrt(dot(e.w, e.w)) <= ori_tol;
       if (conv || it == max_iters) break;
+#if !defined(__HIP_DEVICE_COMPILE__)
+      const long r0 = g_qp_stats[1], p0 = g_qp_stats[2];
+#endif
       int st = solve_problem<NC, true>(&D, row.data(), qc, fk, dt, 1.0 / dt, damping, x, vrow, act, upper, it > 0, hbuf, 1);
+#if !defined(__HIP_DEVICE_COMPILE__)
+      if (g_trace && it < g_trace_iters) {
+        g_trace[((size_t)b * g_trace_iters + it) * 2] = (int32_t)(g_qp_stats[1] - r0);
+        g_trace[((size_t)b * g_trace_iters + it) * 2 + 1] = (int32_t)(g_qp_stats[2] - p0);
+      }
+#endif
       status = std::max(status, st);
       iters = it + 1;
       for (int k = 0; k < NC; ++k) {
         double vk = x[k] * (1.0 / dt);
         x[k] = vk;
         qc[k] = qc[k] + dt * vk;
-        if (D.seg[k].dof >= 0) row[D.seg[k].qadr] = qc[k];
+        if (D.seg_dof[k] >= 0) row[D.seg_qadr[k]] = qc[k];
       }
     }
     if (vrow)
       for (int k = 0; k < NC; ++k)
-        if (D.seg[k].dof >= 0) vrow[D.seg[k].dof] = x[k];
+        if (D.seg_dof[k] >= 0) vrow[D.seg_dof[k]] = x[k];
     status_out[b] = status;
     if (iters_out) iters_out[b] = iters;
     if (err) {
@@ -125,6 +139,13 @@ extern "C" int hostsim_iterate(const mk_model_desc* md, const mk_task_desc* task
   int rc = build(md, tasks, ntask, limits, nlimit, D, &nk, &stride);
   if (rc != MK_OK) return rc;
   HS_DISPATCH(run_iterate, D, q, targets, stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status)
+}
+
+// buf [B, iters, 2] receives (phase-1 rounds, phase-2 steps) of every solve of the next
+// hostsim_iterate calls; null switches the record off
+extern "C" void hostsim_set_trace(int32_t* buf, int iters) {
+  g_trace = buf;
+  g_trace_iters = iters;
 }
 
 // solves, phase-1 rounds, phase-2 steps, factorizations since the last reset
