@@ -144,6 +144,40 @@ MK_DEV void mk_sincos(double x, double* sn, double* cs) {
   *cs = ok ? c : NAN;
 }
 
+// Keeps the instruction scheduler from moving anything across this point.  The kernels
+// are long straight-line blocks full of scalar loads of per-slot constants; unfenced, the
+// scheduler hoists all of them to the top and spills scalar registers by the hundred.
+// With a fence per slot and the next slot's constants requested one slot ahead, the loads
+// are in flight during the arithmetic of the current slot.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MK_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MK_SCHED_FENCE() ((void)0)
+#endif
+
+// Orders the arithmetic that produces / consumes the given values relative to
+// MK_SCHED_FENCE (a fence alone only orders memory operations while the block is first
+// linearised; arithmetic would still drift away from the loads it was meant to overlap).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MK_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define MK_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+#else
+#define MK_PIN4(a, b, c, d) ((void)0)
+#define MK_PIN3(a, b, c) ((void)0)
+#endif
+
+// A wave-uniform zero the optimiser cannot see through.  Added to the descriptor pointer
+// once per iteration of the solve loop: otherwise every per-slot constant is hoisted out
+// of the loop as loop-invariant, hundreds of scalar registers are spilled to vector lanes
+// and read back with v_readlane inside the loop.
+MK_DEV int mk_opaque_zero() {
+  int z = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+s"(z));
+#endif
+  return z;
+}
+
 // True when no lane of the wave still has `pending` set.
 MK_DEV bool mk_wave_none(bool pending) {
 #if defined(__HIP_DEVICE_COMPILE__)

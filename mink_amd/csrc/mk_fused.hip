@@ -281,9 +281,10 @@ MK_DEV void chain_jac(const MkFusedDesc* __restrict__ D, const double (&qc)[NC],
   Q4 Q = Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]};
   V3 t = v3(D->post_pos[0], D->post_pos[1], D->post_pos[2]);
   M3 R = q2m(Q);
+  MkSegC s = D->segc[NC - 1];
 #pragma unroll
   for (int k = NC - 1; k >= 0; --k) {
-    const MkSegC& s = D->segc[k];
+    const MkSegC nx = D->segc[k > 0 ? k - 1 : 0];   // requested one slot ahead
     const double h = s.hinge;
     const double th = h * qc[k];       // hinge angle (0 for a slide)
     double sn, cs;
@@ -301,7 +302,11 @@ MK_DEV void chain_jac(const MkFusedDesc* __restrict__ D, const double (&qc)[NC],
                      s.pq[3] * cs + s.pq[0] * sn};
     t = qrot(Qs, t) + v3(s.pp[0], s.pp[1], s.pp[2]);
     Q = qmul(Qs, Q);
+    MK_SCHED_FENCE();
+    MK_PIN4(Q.w, Q.x, Q.y, Q.z);
+    MK_PIN3(t.x, t.y, t.z);
     R = q2m(Q);
+    s = nx;
   }
   // (Q, t, R) is now the pose of the task frame in the world
   cj.e = se3_log(qmul(qconj(Q), Qt), mulT(R, pt - t));
@@ -375,8 +380,12 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
   }
 
   double H[NC * (NC + 1) / 2], c[NC], lo[NC], hi[NC];
+  // one row of H per slot, together with the slot's posture terms and box bounds; padding
+  // slots carry W = 1, A = B = 0 and infinite bounds: a decoupled entry with solution 0
+  MkDofC dc = D->sdof[0];
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
+    const MkDofC nx = D->sdof[i + 1 < NC ? i + 1 : i];   // requested one slot ahead
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
       double s = 0.0;
@@ -387,17 +396,14 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
     double s = 0.0;
 #pragma unroll
     for (int r = 0; r < 6; ++r) s += ew[r] * Jw[r][i];
-    c[i] = -s;
-  }
-#pragma unroll
-  for (int k = 0; k < NC; ++k) {
-    // padding slots carry W = 1, A = B = 0 and infinite bounds: a decoupled entry with solution 0
-    const MkDofC& dc = D->sdof[k];
-    H[tri(k, k)] += diag + dc.W;
-    c[k] += dc.B * qc[k] - dc.A;
+    H[tri(i, i)] += diag + dc.W;
+    c[i] = dc.B * qc[i] - dc.A - s;
     const double vb = dt * dc.vmax;
-    hi[k] = fmin(dc.gain * (dc.upper - qc[k]), vb);
-    lo[k] = fmax(-(dc.gain * (qc[k] - dc.lower)), -vb);
+    hi[i] = fmin(dc.gain * (dc.upper - qc[i]), vb);
+    lo[i] = fmax(-(dc.gain * (qc[i] - dc.lower)), -vb);
+    MK_SCHED_FENCE();
+    MK_PIN3(c[i], hi[i], lo[i]);
+    dc = nx;
   }
 
 #if defined(MK_ABLATE) && MK_ABLATE == 2
@@ -423,7 +429,7 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
   // ---- dofs outside the chain: diagonal Hessian, box limits -> clamp ----
   // (the constants of the next dof are fetched while the current one is computed)
   const int nd = D->nd;
-  MkDofC dc = D->ddof[0];
+  dc = D->ddof[0];
   for (int d = 0; d < nd; ++d) {
     const MkDofC nx = D->ddof[d + 1 < MK_MAX_NV ? d + 1 : d];
     const double qi = row[dc.qadr];
@@ -514,7 +520,7 @@ __global__ MK_KERNEL_ATTR void fused_step_kernel(const MkFusedDesc* __restrict__
 }
 
 template <int NC>
-__global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restrict__ D,
+__global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restrict__ D_arg,
                                                            double* __restrict__ q,
                                                            const double* __restrict__ targets, int target_stride,
                                                            double dt, double damping, int B, int max_iters,
@@ -522,6 +528,7 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
                                                            double* __restrict__ v_out, int32_t* __restrict__ iters_out,
                                                            double* __restrict__ err_out,
                                                            int32_t* __restrict__ status_out) {
+  const MkFusedDesc* D = D_arg;
   extern __shared__ double tile[];
   const int nq = D->nq, nv = D->nv;
   const int stride = nq | 1;
@@ -552,6 +559,7 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
   uint32_t act = 0u, upper = 0u;  // active bounds of the previous step: warm start of the next
   double* vrow = (valid && v_out) ? v_out + pb * nv : nullptr;
   for (int it = 0; it <= max_iters; ++it) {
+    const MkFusedDesc* __restrict__ D = D_arg + mk_opaque_zero();   // same descriptor, re-read per iteration
     if (!done) {
       ChainJac<NC> cj;
       chain_jac<NC>(D, qc, Qt, pt, cj);
