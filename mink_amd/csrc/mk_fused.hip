@@ -27,7 +27,7 @@ namespace {
 
 // Optional instrumentation of the host test build only (never in device code).
 #if defined(MK_QP_STATS) && !defined(__HIP_DEVICE_COMPILE__)
-static long g_qp_stats[4];  // solves, phase-1 rounds, phase-2 steps, factorizations
+static long g_qp_stats[5];  // solves, phase-1 rounds, phase-2 steps, factorizations, (spare)
 #define MK_STAT(i) (++g_qp_stats[i])
 #else
 #define MK_STAT(i) ((void)0)

@@ -61,13 +61,15 @@ int run_iterate(const MkFusedDesc& D, double* q, const double* targets, int stri
       const bool conv = it > 0 && sqrt(dot(e.v, e.v)) <= pos_tol && sqrt(dot(e.w, e.w)) <= ori_tol;
       if (conv || it == max_iters) break;
 #if !defined(__HIP_DEVICE_COMPILE__)
-      const long r0 = g_qp_stats[1], p0 = g_qp_stats[2];
+      const long r0 = g_qp_stats[1], p0 = g_qp_stats[2], s0 = g_qp_stats[4];
 #endif
       int st = solve_problem<NC, true>(&D, row.data(), qc, fk, dt, 1.0 / dt, damping, x, vrow, act, upper, it > 0, hbuf, 1);
 #if !defined(__HIP_DEVICE_COMPILE__)
       if (g_trace && it < g_trace_iters) {
-        g_trace[((size_t)b * g_trace_iters + it) * 2] = (int32_t)(g_qp_stats[1] - r0);
-        g_trace[((size_t)b * g_trace_iters + it) * 2 + 1] = (int32_t)(g_qp_stats[2] - p0);
+        int32_t* tr = g_trace + ((size_t)b * g_trace_iters + it) * 3;
+        tr[0] = (int32_t)(g_qp_stats[1] - r0);
+        tr[1] = (int32_t)(g_qp_stats[2] - p0);
+        tr[2] = (int32_t)(g_qp_stats[4] - s0);
       }
 #endif
       status = std::max(status, st);
@@ -141,7 +143,7 @@ extern "C" int hostsim_iterate(const mk_model_desc* md, const mk_task_desc* task
   HS_DISPATCH(run_iterate, D, q, targets, stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status)
 }
 
-// buf [B, iters, 2] receives (phase-1 rounds, phase-2 steps) of every solve of the next
+// buf [B, iters, 3] receives (phase-1 rounds, phase-2 steps, single-change steps) of every solve of the next
 // hostsim_iterate calls; null switches the record off
 extern "C" void hostsim_set_trace(int32_t* buf, int iters) {
   g_trace = buf;

@@ -24,15 +24,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "near":
     base = np.array([o.Configuration(model, q).get_transform_frame_to_world("pinch_site", "site") for q in q0])
     tg = W.offset_targets(base, np.random.default_rng(1))
 h = H._load()
-trace = np.zeros((B, K, 2), dtype=np.int32)
+trace = np.zeros((B, K, 3), dtype=np.int32)
 h.hostsim_set_trace(trace.ctypes.data_as(C.c_void_p), C.c_int(K))
 H.iterate(model, W.task_specs(model, False), W.limit_specs(model, True), q0, tg, W.DT, W.DAMPING, K, -1.0, -1.0)
 h.hostsim_set_trace(None, C.c_int(0))
-r, p = trace[..., 0], trace[..., 1]
+r, p, sg = trace[..., 0], trace[..., 1], trace[..., 2]
 rw = r.reshape(B // 64, 64, K).max(axis=1)
 pw = p.reshape(B // 64, 64, K).max(axis=1)
-print("per lane : rounds %.3f  phase2 %.3f" % (r.mean(), p.mean()))
-print("per wave : rounds %.3f  phase2 %.3f" % (rw.mean(), pw.mean()))
+sw = sg.reshape(B // 64, 64, K).max(axis=1)
+print("per lane : rounds %.3f  phase2 %.3f  single %.3f" % (r.mean(), p.mean(), sg.mean()))
+print("per wave : rounds %.3f  phase2 %.3f  single %.3f" % (rw.mean(), pw.mean(), sw.mean()))
 print("rounds per wave by iteration:", np.round(rw.mean(axis=0), 2).tolist())
 print("phase2 per wave by iteration:", np.round(pw.mean(axis=0), 2).tolist())
 print("hist rounds/lane:", np.bincount(r.ravel())[:10].tolist(), " rounds/wave:", np.bincount(rw.ravel())[:12].tolist())
