@@ -94,3 +94,53 @@ def offset_targets(poses: np.ndarray, rng: np.random.Generator) -> np.ndarray:
         a[:, 0] * b[:, 2] - a[:, 1] * b[:, 3] + a[:, 2] * b[:, 0] + a[:, 3] * b[:, 1],
         a[:, 0] * b[:, 3] + a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1] + a[:, 3] * b[:, 0]], -1)
     return np.concatenate([qn, t], axis=1)
+
+
+# ---- BASELINE config 4: Frame + RelativeFrame + Posture, Configuration + Velocity +
+# CollisionAvoidance over the primitive pairs {gripper pads} x {cube, floor} ----
+PADS = ("right_pad1", "right_pad2", "left_pad1", "left_pad2")
+
+
+def config4_specs(model):
+    from .limits import CollisionAvoidanceLimit
+    rel = dict(type=L.TASK_RELATIVE_FRAME, frame_type=L.FRAME_TYPES["site"], frame_id=model.site_id("pinch_site"),
+               root_type=L.FRAME_TYPES["body"], root_id=model.body_id("base_link"), cost=np.ones(6), gain=1.0,
+               lm_damping=0.0)
+    base = task_specs(model, False)
+    coll = CollisionAvoidanceLimit(model, [(list(PADS), ["cube_geom", "floor"])])
+    return [base[0], rel, base[1]], limit_specs(model, True) + [coll._spec(model)]
+
+
+def config4_inputs(model, dmodel, n, seed, near_fraction=0.25):
+    """(q [n, nq], targets [n, 14]) on the device: start configurations with the cube placed
+    within 2 cm of a gripper pad in `near_fraction` of the problems (so that collision rows
+    are active), world and base-relative pose targets from an independent sample."""
+    import torch
+    rng = np.random.default_rng(seed)
+    q = sample_q(model, rng, n)
+    qs = sample_q(model, rng, n)
+    dev = dmodel.device
+    tq = torch.tensor(q, device=dev)
+    k = int(n * near_fraction)
+    if k:
+        pad_ids = np.array([model.geom_id(p) for p in PADS])
+        pick = rng.integers(0, 4, k)
+        pos = np.empty((k, 3))
+        for j, gid in enumerate(pad_ids):
+            sel = np.nonzero(pick == j)[0]
+            if len(sel):
+                pos[sel] = dmodel.frame_pose(tq[sel].contiguous(), L.FRAME_TYPES["geom"], int(gid))[:, 4:].cpu().numpy()
+        d = rng.normal(size=(k, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        free_adr = int(model.jnt_qposadr[model.joint_id("interactive_obj_freejoint")])
+        q[:k, free_adr:free_adr + 3] = pos + d * rng.uniform(0.03, 0.05, (k, 1))
+        qq = rng.normal(size=(k, 4))
+        q[:k, free_adr + 3:free_adr + 7] = qq / np.linalg.norm(qq, axis=1, keepdims=True)
+        tq = torch.tensor(q, device=dev)
+    ts = torch.tensor(qs, device=dev)
+    site, base = model.site_id("pinch_site"), model.body_id("base_link")
+    t_world = dmodel.frame_pose(ts, L.FRAME_TYPES["site"], site)
+    t_base = dmodel.frame_pose(ts, L.FRAME_TYPES["body"], base)
+    from .lie import SE3
+    t_rel = (SE3(t_base).inverse() @ SE3(t_world)).wxyz_xyz
+    return tq, torch.cat([t_world, t_rel], dim=1).contiguous()
