@@ -460,10 +460,14 @@ bool build_dense(const HostModel& m, const mk_task_desc* tasks, int ntask, const
       O.relax = L.bound_relaxation;
       if (upload(allocs, idx, &O.index) != MK_OK) { why = g_last_error; return false; }
       rows += O.n;
+      D.n_general += O.n;
     }
   }
   D.n_rows = rows;
-  if (mk_dense_lds_bytes(m.nv, rows) == 0) { why = "problem does not fit the LDS budget of the dense kernels"; return false; }
+  int npath = 0;   // total length of the root -> body paths
+  for (int b = 0; b < m.nbody; ++b)
+    for (int x = b; x != 0; x = m.body_parentid[x]) ++npath;
+  if (mk_dense_lds_bytes(m.nv, D.n_general, m.nq, D.target_stride, m.nbody, m.njnt, npath) == 0) { why = "problem does not fit the LDS budget of the dense kernels"; return false; }
   return true;
 }
 
@@ -582,6 +586,18 @@ int mk_model_create(const mk_model_desc* d, mk_model** out) {
   if (rc == MK_OK) rc = upload(m->allocs, path_adr, &dv.path_adr);
   if (rc == MK_OK) rc = upload(m->allocs, path_len, &dv.path_len);
   if (rc == MK_OK) rc = upload(m->allocs, path_data, &dv.path_data);
+  dv.npath = (int32_t)path_data.size();
+  if (h.nv <= 64) {
+    std::vector<uint64_t> mask(h.nbody, 0);   // bodies are ordered parents first
+    for (int b = 1; b < h.nbody; ++b) {
+      mask[b] = mask[h.body_parentid[b]];
+      for (int j = h.body_jntadr[b]; j >= 0 && j < h.body_jntadr[b] + h.body_jntnum[b]; ++j) {
+        const int t = h.jnt_type[j], w = t == MK_JNT_FREE ? 6 : t == MK_JNT_BALL ? 3 : 1;
+        for (int k = 0; k < w; ++k) mask[b] |= 1ull << (h.jnt_dofadr[j] + k);
+      }
+    }
+    if (rc == MK_OK) rc = upload(m->allocs, mask, &dv.body_dofmask);
+  }
   if (rc != MK_OK) { mk_model_destroy(m); return rc; }
   *out = m;
   return MK_OK;
@@ -686,7 +702,7 @@ int mk_solve_ik_batch(const mk_problem* p, const double* d_q, const double* d_ta
   if (!d_q || !d_v || !d_status) return fail(MK_ERR_INVALID, "null argument");
   if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
   if (!p->fused) {
-    MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, d_q, d_targets, p->info.target_stride, dt,
+    MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets, p->info.target_stride, dt,
                            damping, B, nullptr, nullptr, nullptr, nullptr, d_v, d_status, -1, nullptr, nullptr,
                            static_cast<hipStream_t>(stream)));
     return MK_OK;
@@ -762,7 +778,7 @@ int mk_build_qp_batch(const mk_problem* p, const double* d_q, const double* d_ta
   if (p->info.n_rows > 0 && (!d_G || !d_h)) return fail(MK_ERR_INVALID, "G and h are required when the problem has limits");
   if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
   if (!p->dense) return fail(MK_ERR_UNSUPPORTED, "dense path unavailable: %s", p->dense_why.c_str());
-  MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, d_q, d_targets, p->info.target_stride, dt, damping,
+  MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets, p->info.target_stride, dt, damping,
                          B, d_P, d_c, p->info.n_rows > 0 ? d_G : nullptr, d_h, nullptr, nullptr, -1, nullptr, nullptr,
                          static_cast<hipStream_t>(stream)));
   return MK_OK;
@@ -776,7 +792,7 @@ int mk_task_eval_batch(const mk_problem* p, int32_t task, const double* d_q, con
   if (!d_q || (!d_err && !d_jac)) return fail(MK_ERR_INVALID, "null argument");
   if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
   if (!p->dense) return fail(MK_ERR_UNSUPPORTED, "dense path unavailable: %s", p->dense_why.c_str());
-  MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, d_q, d_targets, p->info.target_stride, 1.0, 0.0, B,
+  MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets, p->info.target_stride, 1.0, 0.0, B,
                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, task, d_err, d_jac,
                          static_cast<hipStream_t>(stream)));
   return MK_OK;
@@ -787,7 +803,7 @@ int mk_qp_solve_batch(const double* d_P, const double* d_c, const double* d_G, c
   if (n <= 0 || m < 0 || B < 0) return fail(MK_ERR_INVALID, "n, m or B out of range");
   if (B == 0) return MK_OK;
   if (!d_P || !d_c || !d_x || !d_status || (m > 0 && (!d_G || !d_h))) return fail(MK_ERR_INVALID, "null argument");
-  if (mk_dense_lds_bytes(n, m) == 0) return fail(MK_ERR_UNSUPPORTED, "QP too large for the LDS-resident solver (n <= 64 and (4 n^2 + m n) * 8 bytes <= ~150 KB)");
+  if (mk_dense_lds_bytes(n, m, 0, 0, 0, 0, 0) == 0) return fail(MK_ERR_UNSUPPORTED, "QP too large for the LDS-resident solver (n <= 64 and about (4 n^2 + m n) * 8 bytes <= 150 KB)");
   MK_HIP(mk_dense_qp_launch(d_P, d_c, d_G, d_h, n, m, B, d_x, d_status, static_cast<hipStream_t>(stream)));
   return MK_OK;
 }

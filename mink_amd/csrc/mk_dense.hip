@@ -2,19 +2,27 @@
 //
 // Used for task / limit sets outside the structured form of the fused kernels
 // (RelativeFrameTask, ComTask, several frame tasks, CollisionAvoidanceLimit, free or
-// ball joints on a task chain).  Lane i of the wave owns dof i: column i of every task
-// Jacobian, row i of the Hessian.  All lanes walk the same kinematic path, so control
-// flow is wave-uniform and the stacked QP
-//     P = damping I + sum_t (Jw'Jw + mu I),  c = -sum_t ew'Jw      (mink/solve_ik.py:13-22)
-//     G, h = vstack / hstack of the limits                          (mink/solve_ik.py:25-40)
-// is assembled in LDS, then either written out (mink.build_ik), or solved in place by
-// the Goldfarb-Idnani dual active-set method (the algorithm of the reference's QP
-// backend, quadprog) with wave-level reductions, giving v = dq / dt.
+// ball joints on a task chain) and for mink.build_ik / Task.compute_* / qpsolvers-style
+// QP solves.  Per problem, with lane i of the wave owning dof i:
+//   1. forward kinematics of the whole tree, one body per lane (each lane walks the path
+//      root -> its body), body poses and per-dof world axes / anchors parked in LDS
+//      (mj_kinematics; the anchors and axes replace cdof of mj_comPos);
+//   2. every frame / contact-point Jacobian column is then O(1) per lane: the dof is on
+//      the path of the body iff its bit is set in the body's ancestor-dof mask (mj_jac);
+//   3. P = damping I + sum_t (Jw'Jw + mu I), c = -sum_t ew'Jw  (mink/solve_ik.py:13-22),
+//      row i of P accumulated by lane i in LDS;
+//   4. limits: ConfigurationLimit / VelocityLimit rows are +-e_i, kept as two bounds per
+//      lane; CollisionAvoidanceLimit rows are general rows in LDS, with the box-box
+//      closest-feature search spread over the lanes (mink/solve_ik.py:25-40);
+//   5. the Goldfarb-Idnani dual active-set method (the algorithm of the reference's QP
+//      backend, quadprog), v = dq / dt.
 #include "mk_generic.h"
 
 #include "../../include/mink_amd.h"
 #include "mk_device.h"
 #include "mk_tree.h"
+
+#include <algorithm>
 
 namespace {
 
@@ -28,55 +36,25 @@ MK_GPU double wave_sum(double v) {
   return v;
 }
 MK_GPU double bcast(double v, int lane) { return __shfl(v, lane); }
+MK_GPU V3 bcast3(V3 v, int lane) { return v3(__shfl(v.x, lane), __shfl(v.y, lane), __shfl(v.z, lane)); }
 
-// ------------------------------------------------------------- kinematics ----
-// Captures, for the lane's own dof, the joint axis / anchor met on a path walk.
-struct LaneCapture {
-  int lane;
-  int on_path;
-  int kind;
-  V3 axis, anchor;
-  MK_GPU void operator()(int dof, int k, V3 ax, V3 an) {
-    if (dof == lane) { on_path = 1; kind = k; axis = ax; anchor = an; }
+// Wave-wide arg-min / arg-max of (key, id); ties go to the smaller id.  Every lane
+// receives the result.
+MK_GPU void wave_argmin(double& key, int& id) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ok = __shfl_xor(key, o);
+    const int oi = __shfl_xor(id, o);
+    if (ok < key || (ok == key && oi < id)) { key = ok; id = oi; }
   }
-  // world-aligned Jacobian column of a point rigidly attached to the walked body
-  MK_GPU V3 jp(V3 point) const {
-    if (!on_path) return v3(0, 0, 0);
-    return kind == MK_COL_ROT ? cross(axis, point - anchor) : axis;
-  }
-  MK_GPU V3 jr() const { return (on_path && kind == MK_COL_ROT) ? axis : v3(0, 0, 0); }
-};
-
-MK_GPU BodyState walk(const MkDevModel& m, const double* qb, int body, LaneCapture& cap) {
-  cap.on_path = 0;
-  cap.kind = MK_COL_LIN;
-  cap.axis = v3(0, 0, 0);
-  cap.anchor = v3(0, 0, 0);
-  BodyState st = body_state_identity();
-  const int adr = m.path_adr[body], len = m.path_len[body];
-  for (int i = 0; i < len; ++i) advance_body<true>(m, qb, m.path_data[adr + i], st, cap);
-  return st;
 }
-
-struct Frame {
-  V3 ps;
-  Q4 Qs;
-  M3 Rs;
-  V3 bl, ba;   // this lane's body-frame Jacobian column (linear; angular)
-};
-
-MK_GPU Frame eval_frame(const MkDevModel& m, const double* qb, int body, const double* lpos, const double* lquat,
-                        int lane) {
-  LaneCapture cap;
-  cap.lane = lane;
-  BodyState st = walk(m, qb, body, cap);
-  Frame f;
-  f.ps = st.p + mul(st.R, v3(lpos[0], lpos[1], lpos[2]));
-  f.Qs = qmul(st.Q, Q4{lquat[0], lquat[1], lquat[2], lquat[3]});
-  f.Rs = q2m(f.Qs);
-  f.bl = mulT(f.Rs, cap.jp(f.ps));
-  f.ba = mulT(f.Rs, cap.jr());
-  return f;
+MK_GPU void wave_argmax(double& key, int& id) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ok = __shfl_xor(key, o);
+    const int oi = __shfl_xor(id, o);
+    if (ok > key || (ok == key && oi >= 0 && (id < 0 || oi < id))) { key = ok; id = oi; }
+  }
 }
 
 // ------------------------------------------------------------ geom distance ----
@@ -147,38 +125,39 @@ MK_GPU void box_edge(V3 c, const M3& r, V3 h, int e, V3& a0, V3& a1) {
   a1 = c + mul(r, v3(hi[0], hi[1], hi[2]));
 }
 
-// Signed distance and witness points of two oriented boxes: separating-axis test for
-// overlap (penetration = smallest overlap, witnesses around the midpoint of the two
-// support points), otherwise exact closest points by enumerating vertex-box and
-// edge-edge pairs in a fixed order (first strict minimum wins).
-MK_GPU Contact box_box(V3 c1, const M3& r1, V3 h1, V3 c2, const M3& r2, V3 h2) {
+// Signed distance and witness points of two oriented boxes, computed by the whole wave:
+// separating-axis test for overlap (one candidate axis per lane; penetration = smallest
+// overlap, witnesses around the midpoint of the two support points), otherwise exact
+// closest points over the 8 + 8 vertex-box and 12 x 12 edge-edge candidates, spread over
+// the lanes.  Candidates are numbered in a fixed order and the first strict minimum wins,
+// so the result does not depend on how they are distributed.
+MK_GPU Contact box_box_wave(int lane, V3 c1, const M3& r1, V3 h1, V3 c2, const M3& r2, V3 h2) {
   const V3 d = c2 - c1;
-  double best_overlap = INFINITY;
-  V3 best_axis = v3(1, 0, 0);
-  bool separated = false;
-  for (int k = 0; k < 15 && !separated; ++k) {
+  double overlap = INFINITY;
+  V3 axis = v3(1, 0, 0);
+  bool sep = false;
+  if (lane < 15) {
     V3 ax;
-    if (k < 3) ax = col(r1, k);
-    else if (k < 6) ax = col(r2, k - 3);
-    else ax = cross(col(r1, (k - 6) / 3), col(r2, (k - 6) % 3));
+    if (lane < 3) ax = col(r1, lane);
+    else if (lane < 6) ax = col(r2, lane - 3);
+    else ax = cross(col(r1, (lane - 6) / 3), col(r2, (lane - 6) % 3));
     const double n2 = dot(ax, ax);
-    if (n2 < 1e-12) continue;
-    ax = (1.0 / sqrt(n2)) * ax;
-    const V3 a1 = mulT(r1, ax), a2 = mulT(r2, ax);
-    const double ra = fabs(a1.x) * h1.x + fabs(a1.y) * h1.y + fabs(a1.z) * h1.z;
-    const double rb = fabs(a2.x) * h2.x + fabs(a2.y) * h2.y + fabs(a2.z) * h2.z;
-    const double proj = dot(d, ax);
-    const double overlap = ra + rb - fabs(proj);
-    if (overlap < 0.0) {
-      separated = true;
-    } else if (overlap < best_overlap) {
-      best_overlap = overlap;
-      best_axis = proj >= 0.0 ? ax : neg(ax);
+    if (n2 >= 1e-12) {
+      ax = (1.0 / sqrt(n2)) * ax;
+      const V3 a1 = mulT(r1, ax), a2 = mulT(r2, ax);
+      const double ra = fabs(a1.x) * h1.x + fabs(a1.y) * h1.y + fabs(a1.z) * h1.z;
+      const double rb = fabs(a2.x) * h2.x + fabs(a2.y) * h2.y + fabs(a2.z) * h2.z;
+      const double proj = dot(d, ax);
+      overlap = ra + rb - fabs(proj);
+      sep = overlap < 0.0;
+      axis = proj >= 0.0 ? ax : neg(ax);
     }
   }
   Contact ct;
-  if (!separated) {
-    const V3 n = best_axis;
+  if (__ballot(sep) == 0ull) {
+    int id = lane;
+    wave_argmin(overlap, id);
+    const V3 n = bcast3(axis, id);
     const V3 a1 = mulT(r1, n), a2 = mulT(r2, n);
     // support features along n: a component of n that vanishes in a box frame selects the
     // middle of that extent (face / edge centre), not an arbitrary vertex
@@ -186,43 +165,43 @@ MK_GPU Contact box_box(V3 c1, const M3& r1, V3 h1, V3 c2, const M3& r2, V3 h2) {
     const V3 s1 = c1 + mul(r1, v3(sg(a1.x) * h1.x, sg(a1.y) * h1.y, sg(a1.z) * h1.z));
     const V3 s2 = c2 + mul(r2, v3(-sg(a2.x) * h2.x, -sg(a2.y) * h2.y, -sg(a2.z) * h2.z));
     const V3 pos = 0.5 * (s1 + s2);
-    ct.dist = -best_overlap;
+    ct.dist = -overlap;
     ct.p1 = pos - (0.5 * ct.dist) * n;
     ct.p2 = pos + (0.5 * ct.dist) * n;
     return ct;
   }
   double best = INFINITY;
-  ct.p1 = c1;
-  ct.p2 = c2;
-  for (int k = 0; k < 8; ++k) {
-    const V3 v = box_vertex(c1, r1, h1, k), w = box_closest(v, c2, r2, h2);
-    const double dd = dot(v - w, v - w);
-    if (dd < best) { best = dd; ct.p1 = v; ct.p2 = w; }
-  }
-  for (int k = 0; k < 8; ++k) {
-    const V3 v = box_vertex(c2, r2, h2, k), w = box_closest(v, c1, r1, h1);
-    const double dd = dot(v - w, v - w);
-    if (dd < best) { best = dd; ct.p1 = w; ct.p2 = v; }
-  }
-  for (int ea = 0; ea < 12; ++ea) {
-    V3 a0, a1;
-    box_edge(c1, r1, h1, ea, a0, a1);
-    for (int eb = 0; eb < 12; ++eb) {
-      V3 b0, b1, u, w;
-      box_edge(c2, r2, h2, eb, b0, b1);
+  int bi = 1 << 30;
+  V3 p1 = c1, p2 = c2;
+  for (int cnd = lane; cnd < 160; cnd += 64) {
+    V3 u, w;
+    if (cnd < 8) {
+      u = box_vertex(c1, r1, h1, cnd);
+      w = box_closest(u, c2, r2, h2);
+    } else if (cnd < 16) {
+      w = box_vertex(c2, r2, h2, cnd - 8);
+      u = box_closest(w, c1, r1, h1);
+    } else {
+      V3 a0, a1, b0, b1;
+      box_edge(c1, r1, h1, (cnd - 16) / 12, a0, a1);
+      box_edge(c2, r2, h2, (cnd - 16) % 12, b0, b1);
       seg_seg(a0, a1, b0, b1, u, w);
-      const double dd = dot(u - w, u - w);
-      if (dd < best) { best = dd; ct.p1 = u; ct.p2 = w; }
     }
+    const double dd = dot(u - w, u - w);
+    if (dd < best) { best = dd; bi = cnd; p1 = u; p2 = w; }
   }
+  wave_argmin(best, bi);
+  const int src = bi & 63;   // candidate c lives on lane c mod 64
+  ct.p1 = bcast3(p1, src);
+  ct.p2 = bcast3(p2, src);
   ct.dist = sqrt(best);
   return ct;
 }
 
-// mj_geomDistance for the supported primitive pairs (types already ordered t1 <= t2).
-// Returns false for "farther than distmax".
-MK_GPU bool geom_distance(int t1, V3 c1, const M3& r1, V3 s1, int t2, V3 c2, const M3& r2, V3 s2, double distmax,
-                          Contact& ct) {
+// mj_geomDistance for the supported primitive pairs (types already ordered t1 <= t2);
+// all arguments are wave-uniform.  Returns false for "farther than distmax".
+MK_GPU bool geom_distance(int lane, int t1, V3 c1, const M3& r1, V3 s1, int t2, V3 c2, const M3& r2, V3 s2,
+                          double distmax, Contact& ct) {
   if (t1 == GEOM_PLANE && t2 == GEOM_BOX) {
     const V3 n = col(r1, 2);
     double best = INFINITY;
@@ -253,482 +232,687 @@ MK_GPU bool geom_distance(int t1, V3 c1, const M3& r1, V3 s1, int t2, V3 c2, con
     const V3 d = c2 - c1;
     const double far = sqrt(dot(d, d)) - sqrt(dot(s1, s1)) - sqrt(dot(s2, s2));
     if (far >= distmax) return false;
-    ct = box_box(c1, r1, s1, c2, r2, s2);
+    ct = box_box_wave(lane, c1, r1, s1, c2, r2, s2);
   }
   return ct.dist < distmax;
 }
 
-// ------------------------------------------------------------------ QP ----
-// LDS carve-up for one problem (doubles unless noted).
-struct Lds {
-  double *P, *HiN, *M, *LM, *G, *h, *rn, *c, *xs, *Linv, *u, *rv;
-  int32_t* act;
-  uint8_t* is_act;
+// ------------------------------------------------------------------ LDS ----
+// Carve-up of the block's LDS for one problem (n dofs, mg general rows).  Matrices
+// are stored by rows with an odd stride, so that "lane i reads element k of row i" and
+// "all lanes read element (j, k)" are both free of bank conflicts.
+struct WLds {
+  double *q, *tg, *bpos, *bquat, *daxis, *danch;
+  double *P;     // Hessian rows -> its Cholesky factor -> H^-1
+  double *W;     // task-row exchange buffer while building, then L^-1
+  double *HiN;   // H^-1 n_a for the active constraints a
+  double *Minv;  // (N' H^-1 N)^-1 of the active constraints
+  double *Gg, *hg, *gn;   // general rows, their bounds and norms
+  double *c, *rinv, *xs, *hin, *u, *rr, *rv;
+  int32_t *dkind, *act;
+  uint8_t* gact;
+  int npad, na1;
 };
 
-__host__ __device__ inline size_t lds_doubles(int n, int m) {
-  return (size_t)4 * n * n + (size_t)m * n + 2 * (size_t)m + 5 * (size_t)n;
+// Buffers that are only live while the QP is being built (inputs, body poses, dof axes,
+// task rows) share their space with buffers that only the solver uses (Minv, W / HiN).
+__host__ __device__ inline size_t wave_lds_doubles(int n, int mg, int nq, int ts, int nbody) {
+  const size_t npad = (size_t)n | 1, na1 = (size_t)(n + 1) | 1;
+  const size_t build = (size_t)nq + ts + 7 * (size_t)nbody + 6 * (size_t)n + (n + 1) / 2 + 1;   // q, tg, poses, axes, anchors, dkind
+  const size_t qp1 = n * na1;                                                                    // Minv
+  const size_t shared1 = build > qp1 ? build : qp1;
+  const size_t w = n * npad > 6 * (size_t)n ? n * npad : 6 * (size_t)n;                          // W = L^-1, later HiN; task rows
+  return shared1 + w + n * npad + mg * npad + 2 * (size_t)mg     // P, Gg, hg, gn
+         + 7 * (size_t)n                                         // c, rinv, xs, hin, u, rr, rv
+         + (size_t)(n + 1) / 2 + (mg + 7) / 8 + 2;               // act (int32), gact (bytes)
 }
 
-MK_GPU Lds carve(double* base, int n, int m) {
-  Lds s;
-  s.P = base;
-  s.HiN = s.P + n * n;
-  s.M = s.HiN + n * n;
-  s.LM = s.M + n * n;
-  s.G = s.LM + n * n;
-  s.h = s.G + (size_t)m * n;
-  s.rn = s.h + m;
-  s.c = s.rn + m;
-  s.xs = s.c + n;
-  s.Linv = s.xs + n;
-  s.u = s.Linv + n;
-  s.rv = s.u + n;
-  s.act = reinterpret_cast<int32_t*>(s.rv + n);
-  s.is_act = reinterpret_cast<uint8_t*>(s.act + n);
+MK_GPU WLds carve(double* base, int n, int mg, int nq, int ts, int nbody) {
+  WLds s;
+  s.npad = n | 1;
+  s.na1 = (n + 1) | 1;
+  double* p = base;
+  // region shared by the build-time buffers and Minv
+  s.q = p;
+  s.tg = s.q + nq;
+  s.bpos = s.tg + ts;
+  s.bquat = s.bpos + 3 * nbody;
+  s.daxis = s.bquat + 4 * nbody;
+  s.danch = s.daxis + 3 * n;
+  s.dkind = reinterpret_cast<int32_t*>(s.danch + 3 * n);
+  s.Minv = p;
+  {
+    const size_t build = (size_t)nq + ts + 7 * (size_t)nbody + 6 * (size_t)n + (n + 1) / 2 + 1;
+    const size_t qp1 = (size_t)n * s.na1;
+    p += build > qp1 ? build : qp1;
+  }
+  s.W = p;
+  s.HiN = p;   // W = L^-1 is dead once H^-1 is formed; HiN is first written after that
+  p += (n * s.npad > 6 * n) ? n * s.npad : 6 * n;
+  s.P = p; p += n * s.npad;
+  s.Gg = p; p += mg * s.npad;
+  s.hg = p; p += mg;
+  s.gn = p; p += mg;
+  s.c = p; p += n;
+  s.rinv = p; p += n;
+  s.xs = p; p += n;
+  s.hin = p; p += n;
+  s.u = p; p += n;
+  s.rr = p; p += n;
+  s.rv = p; p += n;
+  s.act = reinterpret_cast<int32_t*>(p);
+  s.gact = reinterpret_cast<uint8_t*>(s.act + n + (n & 1));
   return s;
 }
 
-// In-place Cholesky of the n x n matrix in LDS (lower triangle, row-major); lane i
-// owns row i.  Returns false when a pivot is not positive.
-MK_GPU bool chol_wave(double* A, double* Linv, int n, int lane) {
+// ------------------------------------------------------------------ QP ----
+// In-place Cholesky of P (rows in LDS); lane i works on row i.  Leaves 1 / L_jj in rinv.
+MK_GPU bool chol_rows(WLds& s, int n, int lane) {
+  const int np = s.npad;
   for (int j = 0; j < n; ++j) {
     double t = 0.0;
     if (lane >= j && lane < n) {
-      t = A[lane * n + j];
-      for (int k = 0; k < j; ++k) t -= A[lane * n + k] * A[j * n + k];
+      const double* ri = s.P + lane * np;
+      const double* rj = s.P + j * np;
+      t = ri[j];
+#pragma unroll 4
+      for (int k = 0; k < j; ++k) t -= ri[k] * rj[k];
     }
     const double d = bcast(t, j);
     if (!(d > 0.0)) return false;
     const double r = 1.0 / sqrt(d);
-    __syncthreads();
-    if (lane >= j && lane < n) A[lane * n + j] = t * r;
-    if (lane == j) Linv[j] = r;
+    if (lane >= j && lane < n) s.P[lane * np + j] = (lane == j) ? d * r : t * r;
+    if (lane == j) s.rinv[j] = r;
     __syncthreads();
   }
   return true;
 }
 
-// Solves (L L') y = b for the per-lane vector b (lane i holds element i).
-MK_GPU double chol_solve_wave(const double* L, const double* Linv, int n, int lane, double b) {
-  for (int j = 0; j < n; ++j) {
-    const double y = bcast(b, j) * Linv[j];
-    if (lane == j) b = y;
-    else if (lane > j && lane < n) b -= L[lane * n + j] * y;
+// P (holding the Cholesky factor L) <- H^-1 = L^-T L^-1, through W = L^-1 (lane j builds
+// column j of W by forward substitution; lane i then builds row i of W'W).
+MK_GPU void invert_from_chol(WLds& s, int n, int lane) {
+  const int np = s.npad;
+  if (lane < n) {
+    for (int i = 0; i < n; ++i) {
+      double t = (i == lane) ? 1.0 : 0.0;
+      const double* li = s.P + i * np;
+#pragma unroll 4
+      for (int k = 0; k < i; ++k) t -= li[k] * s.W[k * np + lane];
+      s.W[i * np + lane] = t * s.rinv[i];
+    }
   }
-  for (int j = n - 1; j >= 0; --j) {
-    const double y = bcast(b, j) * Linv[j];
-    if (lane == j) b = y;
-    else if (lane < j) b -= L[j * n + lane] * y;
+  __syncthreads();
+  if (lane < n) {
+    for (int j = 0; j < n; ++j) {
+      double acc = 0.0;
+#pragma unroll 4
+      for (int k = j; k < n; ++k) acc += s.W[k * np + lane] * s.W[k * np + j];
+      s.P[lane * np + j] = acc;
+    }
   }
-  return b;
+  __syncthreads();
 }
 
-// min 1/2 x'Px + c'x s.t. Gx <= h; P (LDS, overwritten by its Cholesky factor), c, G,
-// h in LDS.  Returns the status; lane i receives x_i.
-MK_GPU int gi_solve(Lds& s, int n, int m, int lane, double& x_out) {
-  if (!chol_wave(s.P, s.Linv, n, lane)) return 3;
-  double x = chol_solve_wave(s.P, s.Linv, n, lane, lane < n ? -s.c[lane] : 0.0);
-  if (m == 0) { x_out = x; return 0; }
-  for (int j = lane; j < m; j += 64) {
-    double acc = 0.0;
-    for (int i = 0; i < n; ++i) acc += s.G[(size_t)j * n + i] * s.G[(size_t)j * n + i];
-    s.rn[j] = sqrt(acc);
-    s.is_act[j] = 0;
+// min 1/2 x'Px + c'x  s.t.  lo_i <= x_i <= hi_i (lane i) and Gg x <= hg (mg general rows),
+// by the Goldfarb-Idnani dual method.  P, c, Gg, hg in LDS (P is overwritten).  Constraint
+// ids: i = upper bound of x_i, n + i = lower bound, 2n + r = general row r.  The inverse of
+// the active constraints' Gram matrix N'H^-1N is kept explicitly and updated by bordering
+// (a constraint joins) or by a rank-one downdate (a constraint leaves); both need only
+// quantities the step computes anyway.  Returns the status; lane i receives x_i.
+MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, double& x_out) {
+  const int np = s.npad, na1 = s.na1;
+  if (!chol_rows(s, n, lane)) return 3;
+  invert_from_chol(s, n, lane);
+  const double* Hi = s.P;   // H^-1, row-major
+  double x = 0.0;
+  if (lane < n) {
+    const double* hr = Hi + lane * np;
+#pragma unroll 4
+    for (int j = 0; j < n; ++j) x -= hr[j] * s.c[j];
   }
+  for (int r = lane; r < mg; r += 64) {
+    double acc = 0.0;
+    for (int j = 0; j < n; ++j) acc += s.Gg[r * np + j] * s.Gg[r * np + j];
+    s.gn[r] = sqrt(acc);
+    s.gact[r] = 0;
+  }
+  bool act_hi = false, act_lo = false;
   int na = 0;
   int status = 1;
-  const int max_iter = 10 * (m + n);
+  const int max_iter = 10 * (mg + 3 * n);
   for (int it = 0; it < max_iter; ++it) {
-    __syncthreads();
+    // ---- most violated constraint (normalised by the row norm) ----
     if (lane < n) s.xs[lane] = x;
     __syncthreads();
-    // most violated constraint (normalised by the row norm)
     double worst = 1e-12;
     int p = -1;
-    for (int j = lane; j < m; j += 64) {
-      if (s.is_act[j] || !(s.rn[j] > 0.0)) continue;
-      double v = -s.h[j];
-      for (int i = 0; i < n; ++i) v += s.G[(size_t)j * n + i] * s.xs[i];
-      v /= s.rn[j];
-      if (v > worst) { worst = v; p = j; }
+    if (lane < n) {
+      if (!act_hi && x - hi > worst) { worst = x - hi; p = lane; }
+      if (!act_lo && lo - x > worst) { worst = lo - x; p = n + lane; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const double ow = __shfl_xor(worst, o);
-      const int op = __shfl_xor(p, o);
-      if (ow > worst || (ow == worst && op >= 0 && (p < 0 || op < p))) { worst = ow; p = op; }
+    for (int r = lane; r < mg; r += 64) {
+      if (s.gact[r] || !(s.gn[r] > 0.0)) continue;
+      double v = -s.hg[r];
+#pragma unroll 4
+      for (int j = 0; j < n; ++j) v += s.Gg[r * np + j] * s.xs[j];
+      v /= s.gn[r];
+      if (v > worst) { worst = v; p = 2 * n + r; }
     }
+    wave_argmax(worst, p);
     if (p < 0) { status = 0; break; }
-    const double np = lane < n ? s.G[(size_t)p * n + lane] : 0.0;
+    // ---- its normal n+, bound, and H^-1 n+ ----
+    double npl = 0.0, hin = 0.0, hp;
+    if (p < 2 * n) {
+      const int j = p < n ? p : p - n;
+      const double sg = p < n ? 1.0 : -1.0;
+      if (lane == j) npl = sg;
+      if (lane < n) hin = sg * Hi[j * np + lane];
+      hp = bcast(p < n ? hi : -lo, j);
+    } else {
+      const int r = p - 2 * n;
+      if (lane < n) {
+        npl = s.Gg[r * np + lane];
+        const double* hr = Hi + lane * np;
+#pragma unroll 4
+        for (int j = 0; j < n; ++j) hin += hr[j] * s.Gg[r * np + j];
+      }
+      hp = s.hg[r];
+    }
+    const double nHn = wave_sum(npl * hin);
+    if (lane < n) s.hin[lane] = hin;
+    __syncthreads();
     double up = 0.0;
     bool failed = false;
     for (;;) {
-      const double hin = chol_solve_wave(s.P, s.Linv, n, lane, np);
-      const double nHn = wave_sum(np * hin);
-      // r = M^-1 N' H^-1 n+ ; M = N' H^-1 N is kept up to date in LDS
-      for (int a = 0; a < na; ++a) {
-        const double ga = lane < n ? s.G[(size_t)s.act[a] * n + lane] : 0.0;
-        const double v = wave_sum(ga * hin);
-        if (lane == 0) s.rv[a] = v;
+      // r = (N'H^-1N)^-1 N'H^-1 n+   (lane a works on active constraint a)
+      double rva = 0.0;
+      if (lane < na) {
+        const int ida = s.act[lane];
+        if (ida < 2 * n) {
+          rva = (ida < n) ? s.hin[ida] : -s.hin[ida - n];
+        } else {
+          const double* g = s.Gg + (ida - 2 * n) * np;
+#pragma unroll 4
+          for (int j = 0; j < n; ++j) rva += g[j] * s.hin[j];
+        }
+        s.rv[lane] = rva;
       }
       __syncthreads();
-      if (na > 0) {
-        // the active set is small: lane 0 factors M and solves for r
-        int ok = 1;
-        if (lane == 0) {
-          for (int j = 0; j < na && ok; ++j) {
-            double d = s.M[j * n + j];
-            for (int k = 0; k < j; ++k) d -= s.LM[j * n + k] * s.LM[j * n + k];
-            if (!(d > 0.0)) { ok = 0; break; }
-            const double sd = sqrt(d);
-            s.LM[j * n + j] = sd;
-            for (int i = j + 1; i < na; ++i) {
-              double t = s.M[i * n + j];
-              for (int k = 0; k < j; ++k) t -= s.LM[i * n + k] * s.LM[j * n + k];
-              s.LM[i * n + j] = t / sd;
-            }
-          }
-          if (ok) {
-            for (int i = 0; i < na; ++i) {
-              double t = s.rv[i];
-              for (int k = 0; k < i; ++k) t -= s.LM[i * n + k] * s.rv[k];
-              s.rv[i] = t / s.LM[i * n + i];
-            }
-            for (int i = na - 1; i >= 0; --i) {
-              double t = s.rv[i];
-              for (int k = i + 1; k < na; ++k) t -= s.LM[k * n + i] * s.rv[k];
-              s.rv[i] = t / s.LM[i * n + i];
-            }
-          }
-        }
-        ok = __shfl(ok, 0);
-        if (!ok) { failed = true; break; }
-        __syncthreads();
+      double ra = 0.0;
+      if (lane < na) {
+        const double* mr = s.Minv + lane * na1;
+#pragma unroll 4
+        for (int b2 = 0; b2 < na; ++b2) ra += mr[b2] * s.rv[b2];
+        s.rr[lane] = ra;
       }
-      double z = hin;
-      for (int a = 0; a < na; ++a) z -= (lane < n ? s.HiN[a * n + lane] : 0.0) * s.rv[a];
-      z = -z;
-      const double nz = -wave_sum(np * z);
+      __syncthreads();
+      // step direction in x
+      double z = 0.0;
+      if (lane < n) {
+        z = hin;
+#pragma unroll 4
+        for (int a = 0; a < na; ++a) z -= s.HiN[a * np + lane] * s.rr[a];
+        z = -z;
+      }
+      const double nz = -wave_sum(npl * z);
       const bool dependent = nz <= 1e-13 * nHn;
+      // largest step that keeps the multipliers non-negative
       double t1 = INFINITY;
-      int kb = -1;
-      for (int a = 0; a < na; ++a) {
-        const double r = s.rv[a];
-        if (r > 0.0 && s.u[a] / r < t1) { t1 = s.u[a] / r; kb = a; }
-      }
-      const double viol = wave_sum(np * x) - s.h[p];
+      int kb = 1 << 30;
+      if (lane < na && ra > 0.0) { t1 = s.u[lane] / ra; kb = lane; }
+      wave_argmin(t1, kb);
+      const double viol = wave_sum(npl * x) - hp;
       const double t2 = dependent ? INFINITY : viol / nz;
       const double t = fmin(t1, t2);
       if (!(t < INFINITY)) { status = 2; failed = true; break; }
       if (!dependent) x += t * z;
-      __syncthreads();
-      if (lane == 0)
-        for (int a = 0; a < na; ++a) s.u[a] -= t * s.rv[a];
+      if (lane < na) s.u[lane] -= t * ra;
       up += t;
-      __syncthreads();
       if (!dependent && t2 <= t1) {
-        // full step: p joins the active set; extend M by its row / column
-        if (lane < n) s.HiN[na * n + lane] = hin;
-        __syncthreads();
-        for (int b2 = 0; b2 <= na; ++b2) {
-          const double v = wave_sum(np * (lane < n ? s.HiN[b2 * n + lane] : 0.0));
-          if (lane == 0) { s.M[na * n + b2] = v; s.M[b2 * n + na] = v; }
+        // full step: p joins the active set
+        const double is = 1.0 / nz;
+        if (lane < n) s.HiN[na * np + lane] = hin;
+        if (lane < na) {
+          double* mr = s.Minv + lane * na1;
+          for (int b2 = 0; b2 < na; ++b2) mr[b2] += ra * s.rr[b2] * is;
+          mr[na] = -ra * is;
+          s.Minv[na * na1 + lane] = -ra * is;
         }
-        if (lane == 0) { s.act[na] = p; s.u[na] = up; s.is_act[p] = 1; }
+        if (lane == 0) {
+          s.Minv[na * na1 + na] = is;
+          s.act[na] = p;
+          s.u[na] = up;
+          if (p >= 2 * n) s.gact[p - 2 * n] = 1;
+        }
+        if (p < n && lane == p) act_hi = true;
+        if (p >= n && p < 2 * n && lane == p - n) act_lo = true;
         ++na;
         __syncthreads();
         break;
       }
       // partial step: the blocking constraint kb leaves the active set
       __syncthreads();
-      if (lane == 0) s.is_act[s.act[kb]] = 0;
-      for (int a = kb; a < na - 1; ++a) {
-        if (lane < n) s.HiN[a * n + lane] = s.HiN[(a + 1) * n + lane];
-        if (lane == 0) { s.act[a] = s.act[a + 1]; s.u[a] = s.u[a + 1]; }
+      const int idk = s.act[kb];
+      if (idk < n) { if (lane == idk) act_hi = false; }
+      else if (idk < 2 * n) { if (lane == idk - n) act_lo = false; }
+      else if (lane == 0) s.gact[idk - 2 * n] = 0;
+      if (lane < na && lane != kb) {
+        double* mr = s.Minv + lane * na1;
+        const double f = mr[kb] / s.Minv[kb * na1 + kb];
+        const double* mk = s.Minv + kb * na1;
+        for (int b2 = 0; b2 < na; ++b2) mr[b2] -= f * mk[b2];
       }
       __syncthreads();
-      // delete row / column kb of M
-      if (lane == 0) {
-        for (int a = kb; a < na - 1; ++a)
-          for (int b2 = 0; b2 < na; ++b2) s.M[a * n + b2] = s.M[(a + 1) * n + b2];
-        for (int a = 0; a < na - 1; ++a)
-          for (int b2 = kb; b2 < na - 1; ++b2) s.M[a * n + b2] = s.M[a * n + b2 + 1];
+      const int last = na - 1;
+      if (kb != last) {
+        // the last active constraint takes slot kb (their order is immaterial)
+        if (lane < na) s.Minv[kb * na1 + lane] = s.Minv[last * na1 + lane];
+        __syncthreads();
+        if (lane < na) s.Minv[lane * na1 + kb] = s.Minv[lane * na1 + last];
+        if (lane < n) s.HiN[kb * np + lane] = s.HiN[last * np + lane];
+        if (lane == 0) { s.act[kb] = s.act[last]; s.u[kb] = s.u[last]; }
       }
       --na;
       __syncthreads();
     }
-    if (failed) { if (status == 1) status = 3; break; }
+    if (failed) break;
   }
   x_out = x;
   return status;
 }
 
+// ------------------------------------------------------------- kinematics ----
+// Writes the world axis / anchor of every dof of the walked body to LDS.
+struct EmitDof {
+  double *daxis, *danch;
+  int32_t* dkind;
+  bool on;
+  MK_GPU void operator()(int dof, int kind, V3 ax, V3 an) {
+    if (!on) return;
+    daxis[3 * dof] = ax.x; daxis[3 * dof + 1] = ax.y; daxis[3 * dof + 2] = ax.z;
+    danch[3 * dof] = an.x; danch[3 * dof + 1] = an.y; danch[3 * dof + 2] = an.z;
+    dkind[dof] = kind;
+  }
+};
+
+// Whole-tree forward kinematics: lane l walks the path root -> body l (+64, ...), so all
+// bodies advance together; the last body of a walk is the lane's own, whose dofs it emits.
+MK_GPU void tree_fk(const MkDevModel& m, WLds& s, int lane) {
+  EmitDof em{s.daxis, s.danch, s.dkind, false};
+  for (int b0 = 0; b0 < m.nbody; b0 += 64) {
+    const int body = b0 + lane;
+    const bool has = body < m.nbody;
+    const int adr = has ? m.path_adr[body] : 0, len = has ? m.path_len[body] : 0;
+    int maxlen = len;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o));
+    BodyState st = body_state_identity();
+    for (int i = 0; i < maxlen; ++i) {
+      if (i < len) {
+        em.on = (i == len - 1);
+        advance_body<true>(m, s.q, m.path_data[adr + i], st, em);
+      }
+    }
+    if (has) {
+      s.bpos[3 * body] = st.p.x; s.bpos[3 * body + 1] = st.p.y; s.bpos[3 * body + 2] = st.p.z;
+      s.bquat[4 * body] = st.Q.w; s.bquat[4 * body + 1] = st.Q.x; s.bquat[4 * body + 2] = st.Q.y;
+      s.bquat[4 * body + 3] = st.Q.z;
+    }
+  }
+  __syncthreads();
+}
+
+// The lane's own dof: how it moves a point attached to a body whose path contains it.
+struct DofCol {
+  V3 axis, anchor;
+  int kind, lane;
+  MK_GPU bool on(uint64_t mask) const { return (mask >> lane) & 1ull; }
+  // world-aligned Jacobian column of a point rigidly attached to a body with ancestor mask `mask`
+  MK_GPU V3 jp(uint64_t mask, V3 point) const {
+    if (!on(mask)) return v3(0, 0, 0);
+    return kind == MK_COL_ROT ? cross(axis, point - anchor) : axis;
+  }
+  MK_GPU V3 jr(uint64_t mask) const { return (on(mask) && kind == MK_COL_ROT) ? axis : v3(0, 0, 0); }
+};
+
+struct Frame {
+  V3 ps;
+  Q4 Qs;
+  M3 Rs;
+  V3 bl, ba;   // this lane's body-frame Jacobian column (linear; angular)
+};
+
+MK_GPU void body_pose(const WLds& s, int body, V3& p, Q4& Q) {
+  p = v3(s.bpos[3 * body], s.bpos[3 * body + 1], s.bpos[3 * body + 2]);
+  Q = Q4{s.bquat[4 * body], s.bquat[4 * body + 1], s.bquat[4 * body + 2], s.bquat[4 * body + 3]};
+}
+
+MK_GPU Frame eval_frame(const MkDevModel& m, const WLds& s, int body, const double* lpos, const double* lquat,
+                        const DofCol& dc) {
+  V3 bp;
+  Q4 bq;
+  body_pose(s, body, bp, bq);
+  const M3 R = q2m(bq);
+  Frame f;
+  f.ps = bp + mul(R, v3(lpos[0], lpos[1], lpos[2]));
+  f.Qs = qmul(bq, Q4{lquat[0], lquat[1], lquat[2], lquat[3]});
+  f.Rs = q2m(f.Qs);
+  const uint64_t mask = m.body_dofmask[body];
+  f.bl = mulT(f.Rs, dc.jp(mask, f.ps));
+  f.ba = mulT(f.Rs, dc.jr(mask));
+  return f;
+}
+
 // ---------------------------------------------------------------- kernels ----
-__global__ __launch_bounds__(64) void dense_kernel(MkDevModel m, const MkDenseProblem* __restrict__ prob, int n_rows,
-                                                   const double* __restrict__ q, const double* __restrict__ targets,
-                                                   int target_stride, double dt, double damping, int B,
-                                                   double* __restrict__ P_out, double* __restrict__ c_out,
-                                                   double* __restrict__ G_out, double* __restrict__ h_out,
-                                                   double* __restrict__ v_out, int32_t* __restrict__ status_out,
-                                                   int eval_task, double* __restrict__ err_out,
-                                                   double* __restrict__ jac_out) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_kernel(MkDevModel m, const MkDenseProblem* __restrict__ prob, int n_rows,
+                                                   int n_general, int npath, const double* __restrict__ q,
+                                                   const double* __restrict__ targets, int target_stride, double dt,
+                                                   double damping, int B, double* __restrict__ P_out,
+                                                   double* __restrict__ c_out, double* __restrict__ G_out,
+                                                   double* __restrict__ h_out, double* __restrict__ v_out,
+                                                   int32_t* __restrict__ status_out, int eval_task,
+                                                   double* __restrict__ err_out, double* __restrict__ jac_out) {
   extern __shared__ double lds_base[];
   const int lane = threadIdx.x;
-  const long b = blockIdx.x;
-  const int n = m.nv, mrows = n_rows;
-  Lds s = carve(lds_base, n, mrows);
-  const double* qb = q + b * m.nq;
-  const double* tg = targets ? targets + b * target_stride : nullptr;
-  for (int idx = lane; idx < n * n; idx += 64) s.P[idx] = (idx / n == idx % n) ? damping : 0.0;
-  if (lane < n) s.c[lane] = 0.0;
-  for (int idx = lane; idx < mrows * n; idx += 64) s.G[idx] = 0.0;
-  __syncthreads();
+  const int n = m.nv, mrows = n_rows, mg = n_general;
+  WLds s = carve(lds_base, n, mg, m.nq, target_stride, m.nbody);
+  const int np = s.npad;
   const bool own = lane < n;
+  for (long b = blockIdx.x; b < B; b += gridDim.x) {
+    // ---- inputs, kinematics ----
+    for (int i = lane; i < m.nq; i += 64) s.q[i] = q[b * m.nq + i];
+    for (int i = lane; i < target_stride; i += 64) s.tg[i] = targets[b * target_stride + i];
+    for (int idx = lane; idx < n * np; idx += 64) s.P[idx] = 0.0;
+    if (own) { s.c[lane] = 0.0; s.dkind[lane] = MK_COL_LIN; }
+    for (int i = lane; i < 3 * n; i += 64) { s.daxis[i] = 0.0; s.danch[i] = 0.0; }
+    __syncthreads();
+    if (own) s.P[lane * np + lane] = damping;
+    tree_fk(m, s, lane);
+    DofCol dc;
+    dc.lane = lane;
+    dc.kind = own ? s.dkind[lane] : MK_COL_LIN;
+    dc.axis = own ? v3(s.daxis[3 * lane], s.daxis[3 * lane + 1], s.daxis[3 * lane + 2]) : v3(0, 0, 0);
+    dc.anchor = own ? v3(s.danch[3 * lane], s.danch[3 * lane + 1], s.danch[3 * lane + 2]) : v3(0, 0, 0);
+    const double* qb = s.q;
+    const double* tg = s.tg;
 
-  // ---- tasks ----
-  for (int t = 0; t < prob->ntask; ++t) {
-    const MkDenseTask& T = prob->task[t];
-    double Jw[6] = {0, 0, 0, 0, 0, 0}, ew[6] = {0, 0, 0, 0, 0, 0};
-    double Jraw[6] = {0, 0, 0, 0, 0, 0}, eraw[6] = {0, 0, 0, 0, 0, 0};
-    int k = 6;
-    if (T.type == MK_TASK_FRAME || T.type == MK_TASK_RELATIVE_FRAME) {
-      const double* tt = tg + T.target_off;
-      const Q4 Qt = Q4{tt[0], tt[1], tt[2], tt[3]};
-      const V3 pt = v3(tt[4], tt[5], tt[6]);
-      Frame f = eval_frame(m, qb, T.body, T.lpos, T.lquat, lane);
-      Twist e;
-      V3 dl, da;
-      double sign;
-      if (T.type == MK_TASK_FRAME) {
-        // e = log(T_wb^-1 T_wt), J = -jlog(T_wt^-1 T_wb) J_b = -ljacinv(e) J_b
-        e = se3_log(qmul(qconj(f.Qs), Qt), mulT(f.Rs, pt - f.ps));
-        dl = f.bl;
-        da = f.ba;
-        sign = -1.0;
-      } else {
-        // e = log(T_rt^-1 T_rf), J = jlog(T_rt^-1 T_rf) (J_f - Ad(T_rf^-1) J_r) = ljacinv(-e) (...)
-        Frame r = eval_frame(m, qb, T.root_body, T.rpos, T.rquat, lane);
-        const Q4 Qrf = qmul(qconj(r.Qs), f.Qs);
-        const V3 trf = mulT(r.Rs, f.ps - r.ps);
-        const M3 Rt = q2m(Qt);
-        e = se3_log(qmul(qconj(Qt), Qrf), mulT(Rt, trf - pt));
-        const M3 Rrf = q2m(Qrf);
-        dl = f.bl - mulT(Rrf, r.bl - cross(trf, r.ba));
-        da = f.ba - mulT(Rrf, r.ba);
-        e = Twist{e.v, e.w};
-        sign = 1.0;
+    // ---- tasks ----
+    for (int t = 0; t < prob->ntask; ++t) {
+      const MkDenseTask& T = prob->task[t];
+      double Jw[6] = {0, 0, 0, 0, 0, 0}, ew[6] = {0, 0, 0, 0, 0, 0};
+      double Jraw[6] = {0, 0, 0, 0, 0, 0}, eraw[6] = {0, 0, 0, 0, 0, 0};
+      int k = 6;
+      if (T.type == MK_TASK_FRAME || T.type == MK_TASK_RELATIVE_FRAME) {
+        const double* tt = tg + T.target_off;
+        const Q4 Qt = Q4{tt[0], tt[1], tt[2], tt[3]};
+        const V3 pt = v3(tt[4], tt[5], tt[6]);
+        Frame f = eval_frame(m, s, T.body, T.lpos, T.lquat, dc);
+        Twist e;
+        V3 dl, da;
+        double sign;
+        if (T.type == MK_TASK_FRAME) {
+          // e = log(T_wb^-1 T_wt), J = -jlog(T_wt^-1 T_wb) J_b = -ljacinv(e) J_b
+          e = se3_log(qmul(qconj(f.Qs), Qt), mulT(f.Rs, pt - f.ps));
+          dl = f.bl;
+          da = f.ba;
+          sign = -1.0;
+        } else {
+          // e = log(T_rt^-1 T_rf), J = jlog(T_rt^-1 T_rf) (J_f - Ad(T_rf^-1) J_r) = ljacinv(-e) (...)
+          Frame r = eval_frame(m, s, T.root_body, T.rpos, T.rquat, dc);
+          const Q4 Qrf = qmul(qconj(r.Qs), f.Qs);
+          const V3 trf = mulT(r.Rs, f.ps - r.ps);
+          const M3 Rt = q2m(Qt);
+          e = se3_log(qmul(qconj(Qt), Qrf), mulT(Rt, trf - pt));
+          const M3 Rrf = q2m(Qrf);
+          dl = f.bl - mulT(Rrf, r.bl - cross(trf, r.ba));
+          da = f.ba - mulT(Rrf, r.ba);
+          sign = 1.0;
+        }
+        // ljacinv of e (frame task) or of -e (relative frame task)
+        Twist arg = sign < 0 ? e : Twist{neg(e.v), neg(e.w)};
+        M3 Ji, Bm;
+        se3_ljacinv_blocks(arg, Ji, Bm);   // I, 0 below the small-angle switch
+        const V3 jl = mul(Ji, dl) + mul(Bm, da);
+        const V3 ja = mul(Ji, da);
+        Jraw[0] = sign * jl.x; Jraw[1] = sign * jl.y; Jraw[2] = sign * jl.z;
+        Jraw[3] = sign * ja.x; Jraw[4] = sign * ja.y; Jraw[5] = sign * ja.z;
+        eraw[0] = e.v.x; eraw[1] = e.v.y; eraw[2] = e.v.z; eraw[3] = e.w.x; eraw[4] = e.w.y; eraw[5] = e.w.z;
+      } else if (T.type == MK_TASK_COM) {
+        k = 3;
+        V3 com = v3(0, 0, 0), acc = v3(0, 0, 0);
+        double mass = 0.0;
+        for (int bi = 0; bi < T.nbodies; ++bi) {
+          const int body = T.bodies[bi];
+          V3 bp;
+          Q4 bq;
+          body_pose(s, body, bp, bq);
+          const V3 xi = bp + mul(q2m(bq), v3(m.body_ipos[3 * body], m.body_ipos[3 * body + 1], m.body_ipos[3 * body + 2]));
+          const double mb = m.body_mass[body];
+          com = com + mb * xi;
+          acc = acc + mb * dc.jp(m.body_dofmask[body], xi);
+          mass += mb;
+        }
+        const double inv = mass >= MK_MINVAL ? 1.0 / mass : 1.0;
+        const double* tt = tg + T.target_off;
+        eraw[0] = inv * com.x - tt[0]; eraw[1] = inv * com.y - tt[1]; eraw[2] = inv * com.z - tt[2];
+        Jraw[0] = inv * acc.x; Jraw[1] = inv * acc.y; Jraw[2] = inv * acc.z;
       }
-      // ljacinv of e (frame task) or of -e (relative frame task)
-      Twist arg = sign < 0 ? e : Twist{neg(e.v), neg(e.w)};
-      M3 Ji, Bm;
-      V3 jl, ja;
-      se3_ljacinv_blocks(arg, Ji, Bm);   // I, 0 below the small-angle switch
-      jl = mul(Ji, dl) + mul(Bm, da);
-      ja = mul(Ji, da);
-      Jraw[0] = sign * jl.x; Jraw[1] = sign * jl.y; Jraw[2] = sign * jl.z;
-      Jraw[3] = sign * ja.x; Jraw[4] = sign * ja.y; Jraw[5] = sign * ja.z;
-      eraw[0] = e.v.x; eraw[1] = e.v.y; eraw[2] = e.v.z; eraw[3] = e.w.x; eraw[4] = e.w.y; eraw[5] = e.w.z;
-    } else if (T.type == MK_TASK_COM) {
-      k = 3;
-      V3 com = v3(0, 0, 0), acc = v3(0, 0, 0);
-      double mass = 0.0;
-      for (int bi = 0; bi < T.nbodies; ++bi) {
-        const int body = T.bodies[bi];
-        LaneCapture cap;
-        cap.lane = lane;
-        BodyState st = walk(m, qb, body, cap);
-        const V3 xi = st.p + mul(st.R, v3(m.body_ipos[3 * body], m.body_ipos[3 * body + 1], m.body_ipos[3 * body + 2]));
-        const double mb = m.body_mass[body];
-        com = com + mb * xi;
-        acc = acc + mb * cap.jp(xi);
-        mass += mb;
+      if (T.type == MK_TASK_POSTURE) {
+        // diagonal task: J = -I on scalar dofs, e = q* - q (free-joint dofs zeroed)
+        double cost = 0.0, e = 0.0;
+        if (own && m.dof_scalar[lane]) {
+          const int qa = m.dof_qadr[lane];
+          cost = T.pcost[lane];
+          e = T.ptarget[qa] - qb[qa];
+        }
+        const double ewi = cost * (-T.gain * e);
+        const double mu = T.lm * wave_sum(ewi * ewi);
+        if (own) {
+          s.P[lane * np + lane] += cost * cost + mu;
+          s.c[lane] += ewi * cost;
+        }
+        if (eval_task == t && own) {
+          if (err_out) err_out[b * n + lane] = e;
+          if (jac_out)
+            for (int j = 0; j < n; ++j) jac_out[(b * n + j) * n + lane] = (j == lane && m.dof_scalar[lane]) ? -1.0 : 0.0;
+        }
+        continue;
       }
-      const double inv = mass >= MK_MINVAL ? 1.0 / mass : 1.0;
-      const double* tt = tg + T.target_off;
-      eraw[0] = inv * com.x - tt[0]; eraw[1] = inv * com.y - tt[1]; eraw[2] = inv * com.z - tt[2];
-      Jraw[0] = inv * acc.x; Jraw[1] = inv * acc.y; Jraw[2] = inv * acc.z;
-    }
-    if (T.type == MK_TASK_POSTURE) {
-      // diagonal task: J = -I on scalar dofs, e = q* - q (free-joint dofs zeroed)
-      double cost = 0.0, e = 0.0;
-      if (own && m.dof_scalar[lane]) {
-        const int qa = m.dof_qadr[lane];
-        cost = T.pcost[lane];
-        e = T.ptarget[qa] - qb[qa];
+      if (!own)
+        for (int r = 0; r < 6; ++r) Jraw[r] = 0.0;
+      double mu = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {   // rows >= k are zero
+        const double cr = r < k ? T.cost[r] : 0.0;
+        Jw[r] = cr * Jraw[r];
+        ew[r] = cr * (-T.gain * eraw[r]);
+        mu += ew[r] * ew[r];
       }
-      const double ewi = cost * (-T.gain * e);
-      const double mu = T.lm * wave_sum(ewi * ewi);
+      mu *= T.lm;
+      // row i of Jw'Jw on lane i: the weighted rows go through LDS
+      __syncthreads();
       if (own) {
-        s.P[lane * n + lane] += cost * cost + mu;
-        s.c[lane] += ewi * cost;
-      }
-      if (eval_task == t && own) {
-        if (err_out) err_out[b * n + lane] = e;
-        if (jac_out)
-          for (int j = 0; j < n; ++j) jac_out[(b * n + j) * n + lane] = (j == lane && m.dof_scalar[lane]) ? -1.0 : 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s.W[r * n + lane] = Jw[r];
       }
       __syncthreads();
-      continue;
-    }
-    if (!own)
-      for (int r = 0; r < 6; ++r) Jraw[r] = 0.0;
-    double mu = 0.0;
-    for (int r = 0; r < k; ++r) {
-      Jw[r] = T.cost[r] * Jraw[r];
-      ew[r] = T.cost[r] * (-T.gain * eraw[r]);
-      mu += ew[r] * ew[r];
-    }
-    mu *= T.lm;
-    for (int j = 0; j < n; ++j) {
-      double acc = 0.0;
-      for (int r = 0; r < k; ++r) acc += Jw[r] * bcast(Jw[r], j);
-      if (own) s.P[lane * n + j] += acc;
-    }
-    if (own) {
-      s.P[lane * n + lane] += mu;
-      double acc = 0.0;
-      for (int r = 0; r < k; ++r) acc += ew[r] * Jw[r];
-      s.c[lane] -= acc;
-    }
-    if (eval_task == t) {
-      if (err_out && lane < k) err_out[b * k + lane] = eraw[lane];
-      if (jac_out && own)
-        for (int r = 0; r < k; ++r) jac_out[(b * k + r) * n + lane] = Jraw[r];
+      if (own) {
+        double* prow = s.P + lane * np;
+#pragma unroll 2
+        for (int j = 0; j < n; ++j) {
+          double acc = 0.0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) acc += Jw[r] * s.W[r * n + j];
+          prow[j] += acc;
+        }
+        prow[lane] += mu;
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc += ew[r] * Jw[r];
+        s.c[lane] -= acc;
+      }
+      if (eval_task == t) {
+        if (err_out && lane < k) {
+          double el = eraw[0];
+#pragma unroll
+          for (int r = 1; r < 6; ++r) el = (lane == r) ? eraw[r] : el;
+          err_out[b * k + lane] = el;
+        }
+        if (jac_out && own) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+            if (r < k) jac_out[(b * k + r) * n + lane] = Jraw[r];
+        }
+      }
     }
     __syncthreads();
-  }
 
-  // ---- limits ----
-  for (int l = 0; l < prob->nlimit; ++l) {
-    const MkDenseLimit& L = prob->limit[l];
-    if (L.type == MK_LIMIT_CONFIGURATION) {
-      for (int kk = 0; kk < L.n; ++kk) {
-        const int j = L.index[kk];
-        const int dof = m.jnt_dofadr[j], qa = m.jnt_qposadr[j];
-        const double lo = m.jnt_range[2 * j] + L.min_dist, hi = m.jnt_range[2 * j + 1] - L.min_dist;
-        if (lane == dof) {
-          s.G[(size_t)(L.row0 + kk) * n + dof] = 1.0;
-          s.G[(size_t)(L.row0 + L.n + kk) * n + dof] = -1.0;
-          s.h[L.row0 + kk] = L.gain * (hi - qb[qa]);
-          s.h[L.row0 + L.n + kk] = L.gain * (qb[qa] - lo);
+    // ---- limits: two bounds per lane, general rows in LDS ----
+    double lo = -INFINITY, hi = INFINITY;
+    double* Gb = G_out ? G_out + b * (long)mrows * n : nullptr;
+    double* hb = h_out ? h_out + b * (long)mrows : nullptr;
+    int grow = 0;
+    for (int l = 0; l < prob->nlimit; ++l) {
+      const MkDenseLimit& L = prob->limit[l];
+      if (L.type == MK_LIMIT_CONFIGURATION) {
+        for (int kk = 0; kk < L.n; ++kk) {
+          const int j = L.index[kk];
+          const int dof = m.jnt_dofadr[j], qa = m.jnt_qposadr[j];
+          const double up = L.gain * (m.jnt_range[2 * j + 1] - L.min_dist - qb[qa]);
+          const double dn = L.gain * (qb[qa] - (m.jnt_range[2 * j] + L.min_dist));
+          if (lane == dof) { hi = fmin(hi, up); lo = fmax(lo, -dn); }
+          if (Gb && own) {
+            Gb[(long)(L.row0 + kk) * n + lane] = lane == dof ? 1.0 : 0.0;
+            Gb[(long)(L.row0 + L.n + kk) * n + lane] = lane == dof ? -1.0 : 0.0;
+          }
+          if (hb && lane == 0) { hb[L.row0 + kk] = up; hb[L.row0 + L.n + kk] = dn; }
         }
-      }
-    } else if (L.type == MK_LIMIT_VELOCITY) {
-      for (int kk = 0; kk < L.n; ++kk) {
-        const int dof = L.index[kk];
-        if (lane == dof) {
-          s.G[(size_t)(L.row0 + kk) * n + dof] = 1.0;
-          s.G[(size_t)(L.row0 + L.n + kk) * n + dof] = -1.0;
-          s.h[L.row0 + kk] = dt * L.vmax[kk];
-          s.h[L.row0 + L.n + kk] = dt * L.vmax[kk];
+      } else if (L.type == MK_LIMIT_VELOCITY) {
+        for (int kk = 0; kk < L.n; ++kk) {
+          const int dof = L.index[kk];
+          const double vb = dt * L.vmax[kk];
+          if (lane == dof) { hi = fmin(hi, vb); lo = fmax(lo, -vb); }
+          if (Gb && own) {
+            Gb[(long)(L.row0 + kk) * n + lane] = lane == dof ? 1.0 : 0.0;
+            Gb[(long)(L.row0 + L.n + kk) * n + lane] = lane == dof ? -1.0 : 0.0;
+          }
+          if (hb && lane == 0) { hb[L.row0 + kk] = vb; hb[L.row0 + L.n + kk] = vb; }
         }
-      }
-    } else {  // collision avoidance: one row per geom pair
-      for (int kk = 0; kk < L.n; ++kk) {
-        int g1 = L.index[2 * kk], g2 = L.index[2 * kk + 1];
-        const bool swap = m.geom_type[g1] > m.geom_type[g2];
-        if (swap) { const int tmp = g1; g1 = g2; g2 = tmp; }
-        LaneCapture c1, c2;
-        c1.lane = c2.lane = lane;
-        const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
-        BodyState s1 = walk(m, qb, b1, c1);
-        BodyState s2 = walk(m, qb, b2, c2);
-        const V3 x1 = s1.p + mul(s1.R, v3(m.geom_pos[3 * g1], m.geom_pos[3 * g1 + 1], m.geom_pos[3 * g1 + 2]));
-        const V3 x2 = s2.p + mul(s2.R, v3(m.geom_pos[3 * g2], m.geom_pos[3 * g2 + 1], m.geom_pos[3 * g2 + 2]));
-        const M3 r1 = q2m(qmul(s1.Q, Q4{m.geom_quat[4 * g1], m.geom_quat[4 * g1 + 1], m.geom_quat[4 * g1 + 2], m.geom_quat[4 * g1 + 3]}));
-        const M3 r2 = q2m(qmul(s2.Q, Q4{m.geom_quat[4 * g2], m.geom_quat[4 * g2 + 1], m.geom_quat[4 * g2 + 2], m.geom_quat[4 * g2 + 3]}));
-        Contact ct;
-        const bool active = geom_distance(
-            m.geom_type[g1], x1, r1, v3(m.geom_size[3 * g1], m.geom_size[3 * g1 + 1], m.geom_size[3 * g1 + 2]),
-            m.geom_type[g2], x2, r2, v3(m.geom_size[3 * g2], m.geom_size[3 * g2 + 1], m.geom_size[3 * g2 + 2]),
-            L.d_detect, ct);
-        const int row = L.row0 + kk;
-        if (!active) {
-          if (lane == 0) s.h[row] = INFINITY;
-          continue;
+      } else {  // collision avoidance: one general row per geom pair
+        for (int kk = 0; kk < L.n; ++kk, ++grow) {
+          int g1 = L.index[2 * kk], g2 = L.index[2 * kk + 1];
+          const bool swap = m.geom_type[g1] > m.geom_type[g2];
+          if (swap) { const int tmp = g1; g1 = g2; g2 = tmp; }
+          const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
+          V3 p1, p2;
+          Q4 q1, q2;
+          body_pose(s, b1, p1, q1);
+          body_pose(s, b2, p2, q2);
+          const V3 x1 = p1 + mul(q2m(q1), v3(m.geom_pos[3 * g1], m.geom_pos[3 * g1 + 1], m.geom_pos[3 * g1 + 2]));
+          const V3 x2 = p2 + mul(q2m(q2), v3(m.geom_pos[3 * g2], m.geom_pos[3 * g2 + 1], m.geom_pos[3 * g2 + 2]));
+          const M3 r1 = q2m(qmul(q1, Q4{m.geom_quat[4 * g1], m.geom_quat[4 * g1 + 1], m.geom_quat[4 * g1 + 2], m.geom_quat[4 * g1 + 3]}));
+          const M3 r2 = q2m(qmul(q2, Q4{m.geom_quat[4 * g2], m.geom_quat[4 * g2 + 1], m.geom_quat[4 * g2 + 2], m.geom_quat[4 * g2 + 3]}));
+          Contact ct;
+          const bool active = geom_distance(
+              lane, m.geom_type[g1], x1, r1, v3(m.geom_size[3 * g1], m.geom_size[3 * g1 + 1], m.geom_size[3 * g1 + 2]),
+              m.geom_type[g2], x2, r2, v3(m.geom_size[3 * g2], m.geom_size[3 * g2 + 1], m.geom_size[3 * g2 + 2]),
+              L.d_detect, ct);
+          const int row = L.row0 + kk;
+          double gval = 0.0, hval = INFINITY;
+          if (active) {
+            // witness points are (on geom1, on geom2) of the *stored* pair order
+            V3 pa = ct.p1, pb = ct.p2;
+            int ba = b1, bb = b2;
+            if (swap) { pa = ct.p2; pb = ct.p1; ba = b2; bb = b1; }
+            V3 dn = pb - pa;
+            const double nn = sqrt(dot(dn, dn));
+            const V3 nrm = nn < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nn) * dn;
+            const V3 dj = dc.jp(m.body_dofmask[bb], pb) - dc.jp(m.body_dofmask[ba], pa);
+            gval = own ? -dot(nrm, dj) : 0.0;
+            hval = ct.dist > L.d_min ? L.gain * (ct.dist - L.d_min) / dt + L.relax : L.relax;
+          }
+          if (own) s.Gg[grow * np + lane] = gval;
+          if (lane == 0) s.hg[grow] = hval;
+          if (Gb && own) Gb[(long)row * n + lane] = gval;
+          if (hb && lane == 0) hb[row] = hval;
         }
-        // witness points are (on geom1, on geom2) of the *stored* pair order
-        V3 pa = ct.p1, pb = ct.p2;
-        LaneCapture *ca = &c1, *cb = &c2;
-        if (swap) { pa = ct.p2; pb = ct.p1; ca = &c2; cb = &c1; }
-        V3 dn = pb - pa;
-        const double nn = sqrt(dot(dn, dn));
-        const V3 nrm = nn < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nn) * dn;
-        const V3 dj = cb->jp(pb) - ca->jp(pa);
-        if (own) s.G[(size_t)row * n + lane] = -dot(nrm, dj);
-        if (lane == 0)
-          s.h[row] = ct.dist > L.d_min ? L.gain * (ct.dist - L.d_min) / dt + L.relax : L.relax;
       }
     }
-  }
-  __syncthreads();
+    __syncthreads();
 
-  // ---- outputs ----
-  if (P_out) {
-    for (int idx = lane; idx < n * n; idx += 64) P_out[b * n * n + idx] = s.P[idx];
-    if (own) c_out[b * n + lane] = s.c[lane];
-    if (G_out) {
-      for (int idx = lane; idx < mrows * n; idx += 64) G_out[b * mrows * n + idx] = s.G[idx];
-      for (int idx = lane; idx < mrows; idx += 64) h_out[b * mrows + idx] = s.h[idx];
+    // ---- outputs ----
+    if (P_out) {
+      for (int idx = lane; idx < n * n; idx += 64) P_out[b * n * n + idx] = s.P[(idx / n) * np + idx % n];
+      if (own) c_out[b * n + lane] = s.c[lane];
     }
-  }
-  if (v_out) {
-    double x;
-    const int st = gi_solve(s, n, mrows, lane, x);
-    if (own) v_out[b * n + lane] = x / dt;
-    if (lane == 0) status_out[b] = st;
+    if (v_out) {
+      double x;
+      const int st = gi_solve(s, n, mg, lane, lo, hi, x);
+      if (own) v_out[b * n + lane] = x / dt;
+      if (lane == 0) status_out[b] = st;
+    }
+    __syncthreads();
   }
 }
 
 __global__ __launch_bounds__(64) void dense_qp_kernel(const double* __restrict__ P, const double* __restrict__ c,
                                                       const double* __restrict__ G, const double* __restrict__ h,
-                                                      int n, int mrows, double* __restrict__ x_out,
+                                                      int n, int mrows, int B, double* __restrict__ x_out,
                                                       int32_t* __restrict__ status_out) {
   extern __shared__ double lds_base[];
   const int lane = threadIdx.x;
-  const long b = blockIdx.x;
-  Lds s = carve(lds_base, n, mrows);
-  for (int idx = lane; idx < n * n; idx += 64) s.P[idx] = P[b * n * n + idx];
-  if (lane < n) s.c[lane] = c[b * n + lane];
-  for (int idx = lane; idx < mrows * n; idx += 64) s.G[idx] = G[b * mrows * n + idx];
-  for (int idx = lane; idx < mrows; idx += 64) s.h[idx] = h[b * mrows + idx];
-  __syncthreads();
-  double x;
-  const int st = gi_solve(s, n, mrows, lane, x);
-  if (lane < n) x_out[b * n + lane] = x;
-  if (lane == 0) status_out[b] = st;
+  WLds s = carve(lds_base, n, mrows, 0, 0, 0);
+  const int np = s.npad;
+  for (long b = blockIdx.x; b < B; b += gridDim.x) {
+    for (int idx = lane; idx < n * n; idx += 64) s.P[(idx / n) * np + idx % n] = P[b * n * n + idx];
+    if (lane < n) s.c[lane] = c[b * n + lane];
+    for (int idx = lane; idx < mrows * n; idx += 64) s.Gg[(idx / n) * np + idx % n] = G[b * mrows * n + idx];
+    for (int idx = lane; idx < mrows; idx += 64) s.hg[idx] = h[b * mrows + idx];
+    __syncthreads();
+    double x;
+    const int st = gi_solve(s, n, mrows, lane, -INFINITY, INFINITY, x);
+    if (lane < n) x_out[b * n + lane] = x;
+    if (lane == 0) status_out[b] = st;
+    __syncthreads();
+  }
 }
 
 }  // namespace
 
-size_t mk_dense_lds_bytes(int nv, int n_rows) {
+size_t mk_dense_lds_bytes(int nv, int n_general, int nq, int target_stride, int nbody, int njnt, int npath) {
   if (nv > MK_DENSE_MAX_NV) return 0;
-  size_t bytes = lds_doubles(nv, n_rows) * sizeof(double) + (size_t)nv * sizeof(int32_t) + (size_t)n_rows + 64;
+  (void)njnt; (void)npath;
+  const size_t bytes = wave_lds_doubles(nv, n_general, nq, target_stride, nbody) * sizeof(double) + 64;
   return bytes <= 150 * 1024 ? bytes : 0;
 }
 
-hipError_t mk_dense_launch(const MkDevModel& m, const MkDenseProblem* d_problem, int n_rows, const double* q,
-                           const double* targets, int target_stride, double dt, double damping, int B, double* P,
-                           double* c, double* G, double* h, double* v, int32_t* status, int eval_task, double* err,
-                           double* jac, hipStream_t s) {
-  const size_t lds = mk_dense_lds_bytes(m.nv, n_rows);
+// Blocks are persistent (each loops over problems), sized to fill the GPU a few times over.
+static int dense_grid(int B, size_t lds) {
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+  return std::max(1, std::min(B, 256 * per_cu * 2));
+}
+
+hipError_t mk_dense_launch(const MkDevModel& m, const MkDenseProblem* d_problem, int n_rows, int n_general,
+                           const double* q, const double* targets, int target_stride, double dt, double damping, int B,
+                           double* P, double* c, double* G, double* h, double* v, int32_t* status, int eval_task,
+                           double* err, double* jac, hipStream_t s) {
+  const size_t lds = mk_dense_lds_bytes(m.nv, n_general, m.nq, target_stride, m.nbody, m.njnt, m.npath);
   if (lds == 0) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dense_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(dense_kernel, dim3(B), dim3(64), lds, s, m, d_problem, n_rows, q, targets, target_stride, dt,
-                     damping, B, P, c, G, h, v, status, eval_task, err, jac);
+  hipLaunchKernelGGL(dense_kernel, dim3(dense_grid(B, lds)), dim3(64), lds, s, m, d_problem, n_rows, n_general, m.npath, q,
+                     targets, target_stride, dt, damping, B, P, c, G, h, v, status, eval_task, err, jac);
   return hipGetLastError();
 }
 
 hipError_t mk_dense_qp_launch(const double* P, const double* c, const double* G, const double* h, int n, int m, int B,
                               double* x, int32_t* status, hipStream_t s) {
-  const size_t lds = mk_dense_lds_bytes(n, m);
+  const size_t lds = mk_dense_lds_bytes(n, m, 0, 0, 0, 0, 0);
   if (lds == 0) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dense_qp_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(dense_qp_kernel, dim3(B), dim3(64), lds, s, P, c, G, h, n, m, x, status);
+  hipLaunchKernelGGL(dense_qp_kernel, dim3(dense_grid(B, lds)), dim3(64), lds, s, P, c, G, h, n, m, B, x, status);
   return hipGetLastError();
 }

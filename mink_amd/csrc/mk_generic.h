@@ -7,6 +7,7 @@
 
 struct MkDevModel {
   int32_t nq, nv, nbody, njnt, ngeom;
+  int32_t npath;   // entries of path_data
   const int32_t *body_parentid, *body_jntadr, *body_jntnum, *body_mocapid;
   const double *body_pos, *body_quat, *body_mass, *body_ipos;
   const int32_t *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
@@ -15,6 +16,7 @@ struct MkDevModel {
   const int32_t *geom_bodyid, *geom_type;
   const double *geom_size, *geom_pos, *geom_quat;
   const int32_t *path_adr, *path_len, *path_data;  // bodies from the root to each body
+  const uint64_t* body_dofmask;                     // per body: bit d set when dof d is on the path root -> body
 };
 
 constexpr int MK_DENSE_MAX_TASKS = 8;
@@ -50,6 +52,7 @@ struct MkDenseLimit {
 
 struct MkDenseProblem {
   int32_t ntask, nlimit, n_rows, target_stride;
+  int32_t n_general, pad;   // rows that are not +-e_i (collision pairs)
   MkDenseTask task[MK_DENSE_MAX_TASKS];
   MkDenseLimit limit[MK_DENSE_MAX_LIMITS];
 };
@@ -62,14 +65,15 @@ hipError_t mk_generic_frame(const MkDevModel& m, const double* q, int B, int bod
 hipError_t mk_generic_check_limits(const MkDevModel& m, const double* q, double tol, int B, int32_t* first,
                                    hipStream_t s);
 
-// Dense path (mk_dense.hip).  Bytes of LDS one problem needs, or 0 if it cannot run.
-size_t mk_dense_lds_bytes(int nv, int n_rows);
+// Dense path (mk_dense.hip).  Bytes of LDS one problem needs, or 0 if it cannot run
+// (n_general = rows other than +-e_i bounds).
+size_t mk_dense_lds_bytes(int nv, int n_general, int nq, int target_stride, int nbody, int njnt, int npath);
 // Builds the QP of every problem and, depending on the outputs given, writes it out
 // (P/c/G/h), solves it (v/status) and/or reports one task's error and Jacobian.
-hipError_t mk_dense_launch(const MkDevModel& m, const MkDenseProblem* d_problem, int n_rows, const double* q,
-                           const double* targets, int target_stride, double dt, double damping, int B, double* P,
-                           double* c, double* G, double* h, double* v, int32_t* status, int eval_task, double* err,
-                           double* jac, hipStream_t s);
+hipError_t mk_dense_launch(const MkDevModel& m, const MkDenseProblem* d_problem, int n_rows, int n_general,
+                           const double* q, const double* targets, int target_stride, double dt, double damping, int B,
+                           double* P, double* c, double* G, double* h, double* v, int32_t* status, int eval_task,
+                           double* err, double* jac, hipStream_t s);
 // Solves caller-provided dense QPs.
 hipError_t mk_dense_qp_launch(const double* P, const double* c, const double* G, const double* h, int n, int m, int B,
                               double* x, int32_t* status, hipStream_t s);
