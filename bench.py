@@ -211,6 +211,19 @@ def main():
             extra["config3_early_exit"] = {"fraction_converged": float(conv.double().mean().item()),
                                            "mean_solves": float(it.mean().item()),
                                            "max_solves": int(it.max().item())}
+            # BASELINE config 4: Frame + RelativeFrame + Posture, Cfg + Vel + CollisionAvoidance over the
+            # primitive pairs {pads} x {cube, floor}; served by the wave-per-problem kernels
+            t4, l4 = W.config4_specs(model)
+            p4 = DeviceProblem(dm, t4, l4)
+            B4 = 262144
+            q4, tg4 = W.config4_inputs(model, dm, B4, 3)
+            v4 = torch.empty((B4, model.nv), dtype=torch.float64, device=device)
+            s4 = torch.empty(B4, dtype=torch.int32, device=device)
+            w4, e4 = time_launches(lambda i: p4.solve(q4, tg4, W.DT, W.DAMPING, v=v4, status=s4), 3, 1, barrier)
+            extra["config4_B262144_collision_relative_frame"] = {
+                "solves_per_s": B4 * 3 / w4, "ms_per_launch": 1e3 * e4 / 3, "kernel": "dense_kernel (one problem per wave)",
+                "status_nonzero": int((s4 != 0).sum().item())}
+            del q4, tg4, v4, s4
             res["other_workloads"] = extra
         if n_gpus == 1 and not args.no_cpu_baseline:
             torch.cuda.synchronize()

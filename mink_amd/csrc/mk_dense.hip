@@ -635,6 +635,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     dc.anchor = own ? v3(s.danch[3 * lane], s.danch[3 * lane + 1], s.danch[3 * lane + 2]) : v3(0, 0, 0);
     const double* qb = s.q;
     const double* tg = s.tg;
+#if defined(MK_DENSE_ABLATE) && MK_DENSE_ABLATE == 1
+    // tuning build only: kinematics alone
+    if (v_out && own) v_out[b * n + lane] = dc.axis.x + dc.anchor.y + s.bpos[3 * (lane % m.nbody)];
+    __syncthreads();
+    continue;
+#endif
 
     // ---- tasks ----
     for (int t = 0; t < prob->ntask; ++t) {
@@ -845,6 +851,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       for (int idx = lane; idx < n * n; idx += 64) P_out[b * n * n + idx] = s.P[(idx / n) * np + idx % n];
       if (own) c_out[b * n + lane] = s.c[lane];
     }
+#if defined(MK_DENSE_ABLATE) && MK_DENSE_ABLATE == 2
+    // tuning build only: kinematics + QP build, no solve
+    if (v_out && own) v_out[b * n + lane] = s.P[lane * np + (lane + 1) % n] + s.c[lane] + lo + hi + (mg ? s.Gg[lane] : 0.0);
+    __syncthreads();
+    continue;
+#endif
     if (v_out) {
       double x;
       const int st = gi_solve(s, n, mg, lane, lo, hi, x);

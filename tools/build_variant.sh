@@ -5,12 +5,19 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_ab
 name=$1; shift
+# flags that name MK_DENSE_* go to the wave-per-problem kernels instead of the fused ones
+dflags=(); fflags=()
+for a in "$@"; do case "$a" in *MK_DENSE_*) dflags+=("$a");; *) fflags+=("$a");; esac; done
+if [ ${#dflags[@]} -gt 0 ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "${dflags[@]}" -c mink_amd/csrc/mk_dense.hip -o build_ab/dense_$name.o
+fi
 for f in mk_generic mk_dense mk_api; do
   if [ ! -f build_ab/$f.o ] || [ mink_amd/csrc/$f.hip -nt build_ab/$f.o ] || [ mink_amd/csrc/mk_device.h -nt build_ab/$f.o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c mink_amd/csrc/$f.hip -o build_ab/$f.o &
   fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c mink_amd/csrc/mk_fused.hip -o build_ab/fused_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "${fflags[@]}" -c mink_amd/csrc/mk_fused.hip -o build_ab/fused_$name.o
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared build_ab/fused_$name.o build_ab/mk_generic.o build_ab/mk_dense.o build_ab/mk_api.o -o build_ab/libmink_$name.so
+dobj=build_ab/mk_dense.o; [ ${#dflags[@]} -gt 0 ] && dobj=build_ab/dense_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared build_ab/fused_$name.o build_ab/mk_generic.o $dobj build_ab/mk_api.o -o build_ab/libmink_$name.so
 echo build_ab/libmink_$name.so
