@@ -374,8 +374,6 @@ bool build_dense(const HostModel& m, const mk_task_desc* tasks, int ntask, const
   memset(&D, 0, sizeof(D));
   if (m.nv > MK_DENSE_MAX_NV) { why = "more than 64 dofs"; return false; }
   if (ntask > MK_DENSE_MAX_TASKS || nlimit > MK_DENSE_MAX_LIMITS) { why = "too many tasks or limits"; return false; }
-  bool has_ball = false;
-  for (int j = 0; j < m.njnt; ++j) has_ball |= m.jnt_type[j] == MK_JNT_BALL;
   D.ntask = ntask;
   D.nlimit = nlimit;
   int off = 0;
@@ -395,7 +393,6 @@ bool build_dense(const HostModel& m, const mk_task_desc* tasks, int ntask, const
       O.k = 6;
       off += 7;
     } else if (T.type == MK_TASK_POSTURE) {
-      if (has_ball) { why = "posture task on a model with ball joints"; return false; }
       if (T.ncost != m.nv || !T.target_q) { why = "posture task needs nv costs and a target"; return false; }
       std::vector<double> pc(T.cost, T.cost + m.nv), pt(T.target_q, T.target_q + m.nq);
       if (upload(allocs, pc, &O.pcost) != MK_OK || upload(allocs, pt, &O.ptarget) != MK_OK) { why = g_last_error; return false; }
@@ -563,12 +560,13 @@ int mk_model_create(const mk_model_desc* d, mk_model** out) {
     path_len[b] = (int32_t)p.size();
     path_data.insert(path_data.end(), p.begin(), p.end());
   }
-  std::vector<int32_t> dof_qadr(h.nv), dof_scalar(h.nv);
+  std::vector<int32_t> dof_qadr(h.nv), dof_scalar(h.nv), dof_ball(h.nv, -1);
   for (int j = 0; j < h.njnt; ++j) {
     const int t = h.jnt_type[j], w = t == MK_JNT_FREE ? 6 : t == MK_JNT_BALL ? 3 : 1;
     for (int k = 0; k < w; ++k) {
       dof_qadr[h.jnt_dofadr[j] + k] = h.jnt_qposadr[j] + k;
       dof_scalar[h.jnt_dofadr[j] + k] = (t == MK_JNT_HINGE || t == MK_JNT_SLIDE) ? 1 : 0;
+      if (t == MK_JNT_BALL) dof_ball[h.jnt_dofadr[j] + k] = k;
     }
   }
   MkDevModel& dv = m->dev;
@@ -583,6 +581,7 @@ int mk_model_create(const mk_model_desc* d, mk_model** out) {
 #undef UP
   if (rc == MK_OK) rc = upload(m->allocs, dof_qadr, &dv.dof_qadr);
   if (rc == MK_OK) rc = upload(m->allocs, dof_scalar, &dv.dof_scalar);
+  if (rc == MK_OK) rc = upload(m->allocs, dof_ball, &dv.dof_ball);
   if (rc == MK_OK) rc = upload(m->allocs, path_adr, &dv.path_adr);
   if (rc == MK_OK) rc = upload(m->allocs, path_len, &dv.path_len);
   if (rc == MK_OK) rc = upload(m->allocs, path_data, &dv.path_data);

@@ -706,10 +706,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       if (T.type == MK_TASK_POSTURE) {
         // diagonal task: J = -I on scalar dofs, e = q* - q (free-joint dofs zeroed)
         double cost = 0.0, e = 0.0;
+        const int ballk = own ? m.dof_ball[lane] : -1;
         if (own && m.dof_scalar[lane]) {
           const int qa = m.dof_qadr[lane];
           cost = T.pcost[lane];
           e = T.ptarget[qa] - qb[qa];
+        } else if (ballk >= 0) {
+          // mj_differentiatePos for a ball joint: rotation vector of conj(q) * q_target (mju_subQuat)
+          const int qa = m.dof_qadr[lane] - ballk;
+          const Q4 d = qmul(Q4{qb[qa], -qb[qa + 1], -qb[qa + 2], -qb[qa + 3]},
+                            Q4{T.ptarget[qa], T.ptarget[qa + 1], T.ptarget[qa + 2], T.ptarget[qa + 3]});
+          double sn = sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+          V3 ax = v3(1, 0, 0);
+          if (sn < MK_MINVAL) sn = 0.0; else ax = (1.0 / sn) * v3(d.x, d.y, d.z);
+          double speed = 2.0 * atan2(sn, d.w);
+          if (speed > MK_PI) speed -= 2.0 * MK_PI;
+          cost = T.pcost[lane];
+          e = speed * (ballk == 0 ? ax.x : (ballk == 1 ? ax.y : ax.z));
         }
         const double ewi = cost * (-T.gain * e);
         const double mu = T.lm * wave_sum(ewi * ewi);
@@ -720,7 +733,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (eval_task == t && own) {
           if (err_out) err_out[b * n + lane] = e;
           if (jac_out)
-            for (int j = 0; j < n; ++j) jac_out[(b * n + j) * n + lane] = (j == lane && m.dof_scalar[lane]) ? -1.0 : 0.0;
+            for (int j = 0; j < n; ++j)
+              jac_out[(b * n + j) * n + lane] = (j == lane && (m.dof_scalar[lane] || ballk >= 0)) ? -1.0 : 0.0;
         }
         continue;
       }

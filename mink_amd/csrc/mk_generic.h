@@ -13,6 +13,7 @@ struct MkDevModel {
   const int32_t *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
   const double *jnt_pos, *jnt_axis, *jnt_range, *qpos0;
   const int32_t *dof_qadr, *dof_scalar;   // per dof: qpos address, 1 for hinge / slide dofs
+  const int32_t* dof_ball;                // per dof: component 0..2 of a ball joint, else -1
   const int32_t *geom_bodyid, *geom_type;
   const double *geom_size, *geom_pos, *geom_quat;
   const int32_t *path_adr, *path_len, *path_data;  // bodies from the root to each body
