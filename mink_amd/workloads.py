@@ -96,7 +96,7 @@ def offset_targets(poses: np.ndarray, rng: np.random.Generator) -> np.ndarray:
     return np.concatenate([qn, t], axis=1)
 
 
-# ---- BASELINE config 4: Frame + RelativeFrame + Posture, Configuration + Velocity +
+# ---- benchmark config 4: Frame + RelativeFrame + Posture, Configuration + Velocity +
 # CollisionAvoidance over the primitive pairs {gripper pads} x {cube, floor} ----
 PADS = ("right_pad1", "right_pad2", "left_pad1", "left_pad2")
 
