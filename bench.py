@@ -227,6 +227,30 @@ def main():
                 "solves_per_s": B4 * 3 / w4, "ms_per_launch": 1e3 * e4 / 3, "kernel": "dense_kernel (one problem per wave)",
                 "status_nonzero": int((s4 != 0).sum().item())}
             del q4, tg4, v4, s4
+            # kinematic move_to rollouts (waypoint generator + the callers' IK loop per waypoint step)
+            import mink_amd as mk
+            Br = 65536
+            rq = q0[:Br].clone()
+            rcfg = mk.Configuration(model, rq, device=device)
+            start = rcfg.get_transform_frame_to_world("pinch_site", "site")
+            g = torch.Generator(device="cpu").manual_seed(SEED)
+            goal_pos = start.translation() + (torch.rand((Br, 3), generator=g, dtype=torch.float64) * 0.3 - 0.15).to(device)
+            goal_rot = start.rotation() @ mk.SO3.exp((torch.rand((Br, 3), generator=g, dtype=torch.float64) * 0.8 - 0.4).to(device))
+            ftask = mk.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0)
+            ptask = mk.PostureTask(model, cost=W.posture_cost(model))
+            ptask.set_target(W.home_q(model))
+            wcfg = mk.LinearWaypointReachConfig(0.01, 0.08, 0.05, 0.3)
+            torch.cuda.synchronize()
+            tr = time.perf_counter()
+            ro = mk.move_to(rcfg, ftask, [ftask, ptask], goal_pos, goal_rot, wcfg, max_steps=50)
+            torch.cuda.synchronize()
+            tr = time.perf_counter() - tr
+            extra["move_to_rollouts_B65536"] = {
+                "rollouts_per_s": Br / tr, "seconds": tr, "fraction_reached": float(ro["reached"].double().mean().item()),
+                "mean_waypoint_steps": float(ro["steps"].double().mean().item()),
+                "ik_solves_per_s": float(ro["solves"].sum().item()) / tr,
+                "note": "kinematic part of the reference's move_to (waypoint generator + <=20-iteration IK loop per "
+                        "step, default ConfigurationLimit), physics excluded"}
             res["other_workloads"] = extra
         if n_gpus == 1 and not args.no_cpu_baseline:
             torch.cuda.synchronize()

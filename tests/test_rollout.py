@@ -1,0 +1,96 @@
+"""The waypoint-reaching harness against a restatement of the reference's own code
+(envs/robot_utils.py:131-160 with scipy's Rotation / Slerp, envs/mj_env.py:209-276) that
+drives the numpy oracle one problem at a time."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from scipy.spatial.transform import Rotation, Slerp
+
+from mink_amd.lie import SO3
+from mink_amd.rollout import LinearWaypointReach, LinearWaypointReachConfig
+
+CFG = LinearWaypointReachConfig(pos_threshold=0.01, pos_step_size=0.08, rot_threshold=0.05, rot_step_size=0.3)
+
+
+def ref_step(target_pos, target_euler, curr_pos, curr_euler, cfg):
+    """LinearWaypointReach.step of the reference, verbatim in behaviour."""
+    target_rot = Rotation.from_euler("xyz", target_euler)
+    delta = target_pos - curr_pos
+    pos_reached = np.linalg.norm(delta) < cfg.pos_threshold
+    if pos_reached:
+        abs_pos = target_pos
+    else:
+        abs_pos = curr_pos + delta / np.linalg.norm(delta) * min(cfg.pos_step_size, np.linalg.norm(delta))
+    curr_rot = Rotation.from_euler("xyz", curr_euler)
+    half = Slerp([0, 1], Rotation.concatenate([curr_rot, target_rot]))(0.5)
+    rot_reached = np.linalg.norm((target_rot * curr_rot.inv()).as_euler("xyz")) < cfg.rot_threshold
+    return abs_pos, half, bool(pos_reached and rot_reached)
+
+
+def test_waypoint_step_matches_reference_code():
+    rng = np.random.default_rng(0)
+    B = 60
+    tp, te = rng.uniform(-0.5, 0.5, (B, 3)), rng.uniform(-1.5, 1.5, (B, 3))
+    cp = tp + rng.uniform(-0.2, 0.2, (B, 3)) * (rng.random((B, 1)) < 0.8)
+    ce = te + rng.uniform(-0.6, 0.6, (B, 3)) * (rng.random((B, 1)) < 0.8)
+    cp[:5], ce[:5] = tp[:5] + 1e-3, te[:5] + 1e-3
+    e = torch.tensor(ce)
+    p, r, reached = LinearWaypointReach.from_euler(tp, te, CFG).step(
+        torch.tensor(cp), SO3.from_rpy_radians(e[:, 0], e[:, 1], e[:, 2]))
+    assert 0 < int(reached.sum()) < B
+    for b in range(B):
+        ap, half, done = ref_step(tp[b], te[b], cp[b], ce[b], CFG)
+        np.testing.assert_allclose(p[b].numpy(), ap, rtol=0, atol=1e-14)
+        qs, qm = half.as_quat()[[3, 0, 1, 2]], r.wxyz[b].numpy()
+        np.testing.assert_allclose(qm * np.sign(qm @ qs), qs, rtol=0, atol=1e-13)
+        assert bool(reached[b]) == done
+
+
+@pytest.mark.gpu
+def test_move_to_matches_sequential_reference_loop():
+    import mink_amd as mink
+    from mink_amd import workloads as W
+    from oracle import ik_oracle as o
+    model = mink.load_builtin("tidybot_cube")
+    rng = np.random.default_rng(1)
+    B, max_steps = 6, 12
+    q0 = W.sample_q(model, rng, B)
+    cfg = mink.Configuration(model, q0)
+    start = cfg.get_transform_frame_to_world("pinch_site", "site")
+    goal_pos = (start.translation() + torch.tensor(rng.uniform(-0.15, 0.15, (B, 3)), device="cuda:0"))
+    goal_rot = start.rotation() @ SO3.exp(torch.tensor(rng.uniform(-0.4, 0.4, (B, 3)), device="cuda:0"))
+    goal_pos[0] = start.translation()[0] + 0.004          # reached at once
+    goal_rot.wxyz[0] = start.rotation().wxyz[0]
+    frame = mink.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0)
+    posture = mink.PostureTask(model, cost=W.posture_cost(model))
+    posture.set_target(W.home_q(model))
+    out = mink.move_to(cfg, frame, [frame, posture], goal_pos, goal_rot, CFG, max_steps=max_steps)
+    steps = out["steps"].cpu().numpy()
+    assert steps[0] == 1 and bool(out["reached"][0])
+    # the same thing one problem at a time: reference waypoint code + numpy oracle IK
+    gp, gq = goal_pos.cpu().numpy(), goal_rot.wxyz.cpu().numpy()
+    for b in range(B):
+        ocfg = o.Configuration(model, q0[b])
+        goal_euler = Rotation.from_quat(gq[b][[1, 2, 3, 0]]).as_euler("xyz")
+        n_steps, n_solves, reached = 0, 0, False
+        for _ in range(max_steps):
+            T = ocfg.get_transform_frame_to_world("pinch_site", "site")
+            eul = Rotation.from_quat(T[[1, 2, 3, 0]]).as_euler("xyz")
+            pos_cmd, half, reached = ref_step(gp[b], goal_euler, T[4:], eul, CFG)
+            target = np.concatenate([half.as_quat()[[3, 0, 1, 2]], pos_cmd])
+            tasks = [o.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0, target=target),
+                     o.PostureTask(cost=W.posture_cost(model), target_q=W.home_q(model))]
+            for _ in range(20):
+                v = o.solve_ik(ocfg, tasks, 1 / 200, damping=1e-3)
+                ocfg.integrate_inplace(v, 1 / 200)
+                n_solves += 1
+                err = tasks[0].error(ocfg)
+                if np.linalg.norm(err[:3]) <= 1e-4 and np.linalg.norm(err[3:]) <= 1e-4:
+                    break
+            n_steps += 1
+            if reached:
+                break
+        assert steps[b] == n_steps and bool(out["reached"][b]) == reached
+        assert int(out["solves"][b]) == n_solves
+        np.testing.assert_allclose(cfg.q[b].cpu().numpy(), ocfg.q, rtol=0, atol=1e-8)
