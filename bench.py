@@ -119,10 +119,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # MINK_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: the
+    # ranks share the visible devices and the (host-side) collectives run over gloo
+    backend = os.environ.get("MINK_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if world > 1 else 0
+    device = torch.device(f"cuda:{dev_index}")
+    red_device = device if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         barrier = dist.barrier
     else:
         dist = None
@@ -130,7 +139,6 @@ def main():
 
         def barrier():
             return None
-    device = torch.device(f"cuda:{local_rank if world > 1 else 0}")
     n_gpus = world
 
     model = load_builtin("tidybot_cube")
@@ -149,7 +157,7 @@ def main():
         prob.iterate_(qbufs[i], targets, W.DT, W.DAMPING, ITERS, -1.0, -1.0, out=out)
 
     wall, ev = time_launches(step, args.steps, args.warmup, barrier)
-    t = torch.tensor([wall], dtype=torch.float64, device=device)
+    t = torch.tensor([wall], dtype=torch.float64, device=red_device)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
@@ -157,7 +165,7 @@ def main():
     stats = S.reduce_stats(
         {"bad": int((out["status"] != 0).sum().item())},
         {"pos": float(out["err"][:, :3].norm(dim=1).max().item()),
-         "ori": float(out["err"][:, 3:].norm(dim=1).max().item())}, dist, device)
+         "ori": float(out["err"][:, 3:].norm(dim=1).max().item())}, dist, red_device)
     value = solves_per_rank * n_gpus / wall_max
     kernel_s = ev / args.steps                 # average launch duration on this rank (HIP events)
     kernel_rate = B * ITERS / kernel_s
