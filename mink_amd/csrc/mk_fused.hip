@@ -116,7 +116,7 @@ MK_DEV void symv(HView H, const double (&x)[N], double (&y)[N]) {
 //            step of the same problem when warm) and repeats: solve on the face, drop
 //            every bound whose multiplier is negative and (for the first few rounds)
 //            add every violated bound.  A round that changes nothing has found the
-//            optimum outright.  After kGuessRounds the additions stop, so the set only
+//            optimum outright.  After kGuessRounds (3 warm, 6 cold) the additions stop, so the set only
 //            shrinks and ends in an S-pair.
 //   phase 2  is the Goldfarb-Idnani dual method from that S-pair: pick the most violated
 //            inactive bound p and move along the direction that keeps A tight until p
@@ -130,7 +130,9 @@ template <int N>
 MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const double (&hi)[N], double (&x)[N],
                   uint32_t& act_io, uint32_t& upper_io, bool warm) {
   constexpr double kTol = 1e-14;
-  constexpr int kGuessRounds = 6;
+  // a cold start has many bounds to find and profits from more guessing rounds; a warm
+  // start that does not settle quickly is usually cycling and is better off in phase 2
+  const int kGuessRounds = warm ? 3 : 6;
   MK_STAT(0);
   double L[N * (N + 1) / 2], Ld[N];
   double u[N];

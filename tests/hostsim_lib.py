@@ -8,7 +8,7 @@ import numpy as np
 
 from mink_amd import _lib as L
 
-PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "libhostsim.so")
+PATH = os.environ.get("HOSTSIM_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "libhostsim.so")
 
 
 def available():
