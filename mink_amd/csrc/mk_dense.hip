@@ -353,6 +353,71 @@ MK_GPU void invert_from_chol(WLds& s, int n, int lane) {
   __syncthreads();
 }
 
+// Value of `v` on lane `src` (wave-uniform index), delivered through scalar registers:
+// no LDS round trip, and the result can feed vector instructions directly.
+MK_GPU double readlane_f64(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// Register-resident version of chol_rows + invert_from_chol for n <= NP: lane i keeps row
+// i of P / L in registers, then column i of L^-1, then row i of H^-1, and reads other
+// lanes' entries with readlane.  Fully unrolled: about 3 x n^2/2 fused multiply-adds and
+// as many lane reads, no barriers and no LDS traffic until H^-1 is written out.
+template <int NP>
+__device__ __attribute__((noinline)) bool invert_regs(WLds& s, int n, int lane) {
+  const int np = s.npad;
+  double A[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) A[j] = (lane < n && j < n) ? s.P[lane * np + j] : 0.0;
+  // (lane j keeps 1 / L_jj in place of L_jj: only the reciprocal is used afterwards)
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    if (j < n) {
+      // pivot: lane j subtracts the squares of its finished entries
+      double t = A[j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= A[k] * A[k];
+      const double d = readlane_f64(t, j);
+      if (!(d > 0.0)) return false;
+      const double r = 1.0 / sqrt(d);
+      // column j of the other rows
+      double u = A[j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) u -= A[k] * readlane_f64(A[k], j);
+      A[j] = (lane == j) ? r : ((lane > j) ? u * r : 0.0);
+    }
+    MK_SCHED_FENCE();
+  }
+  // column `lane` of W = L^-1 by forward substitution; L_ik comes from lane i
+  double Wc[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    Wc[i] = 0.0;
+    if (i < n) {
+      double t = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) t -= readlane_f64(A[k], i) * Wc[k];
+      Wc[i] = t * readlane_f64(A[i], i);
+    }
+    MK_SCHED_FENCE();
+  }
+  // row `lane` of H^-1 = W'W: (i, j) entry = sum_{k >= j} W_ki W_kj, W_kj from lane j
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    if (j < n) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = j; k < NP; ++k) acc += Wc[k] * readlane_f64(Wc[k], j);
+      if (lane < n) s.P[lane * np + j] = acc;
+    }
+    MK_SCHED_FENCE();
+  }
+  __syncthreads();
+  return true;
+}
+
 // min 1/2 x'Px + c'x  s.t.  lo_i <= x_i <= hi_i (lane i) and Gg x <= hg (mg general rows),
 // by the Goldfarb-Idnani dual method.  P, c, Gg, hg in LDS (P is overwritten).  Constraint
 // ids: i = upper bound of x_i, n + i = lower bound, 2n + r = general row r.  The inverse of
@@ -361,8 +426,14 @@ MK_GPU void invert_from_chol(WLds& s, int n, int lane) {
 // quantities the step computes anyway.  Returns the status; lane i receives x_i.
 MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, double& x_out) {
   const int np = s.npad, na1 = s.na1;
-  if (!chol_rows(s, n, lane)) return 3;
-  invert_from_chol(s, n, lane);
+  if (n <= 16) {
+    if (!invert_regs<16>(s, n, lane)) return 3;
+  } else if (n <= 32) {
+    if (!invert_regs<32>(s, n, lane)) return 3;
+  } else {
+    if (!chol_rows(s, n, lane)) return 3;
+    invert_from_chol(s, n, lane);
+  }
   const double* Hi = s.P;   // H^-1, row-major
   double x = 0.0;
   if (lane < n) {
@@ -376,6 +447,10 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
     s.gn[r] = sqrt(acc);
     s.gact[r] = 0;
   }
+#if defined(MK_DENSE_ABLATE) && MK_DENSE_ABLATE == 3
+  x_out = x;   // tuning build only: factorisation, inverse and the unconstrained minimiser
+  return 0;
+#endif
   bool act_hi = false, act_lo = false;
   int na = 0;
   int status = 1;
