@@ -30,31 +30,67 @@ namespace {
 
 constexpr int GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_BOX = 6;
 
+// Wave-wide reductions with DPP lane moves (row shifts inside the 16-lane rows, then the
+// two row broadcasts): ALU speed, where shuffles through the LDS crossbar cost an LDS
+// round trip per step.  After the scan lane 63 holds the result, read back for all lanes.
+template <int CTRL, int ROW_MASK>
+MK_GPU int dpp_i32(int v, int fill) {
+  return __builtin_amdgcn_update_dpp(fill, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+MK_GPU double dpp_f64(double v, double fill) {
+  const int lo = dpp_i32<CTRL, ROW_MASK>(__double2loint(v), __double2loint(fill));
+  const int hi = dpp_i32<CTRL, ROW_MASK>(__double2hiint(v), __double2hiint(fill));
+  return __hiloint2double(hi, lo);
+}
+MK_GPU double readlane_f64(double v, int src);
+
 MK_GPU double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_f64<0x111, 0xf>(v, 0.0);   // row_shr:1 (lanes without a source add the fill value)
+  v += dpp_f64<0x112, 0xf>(v, 0.0);   // row_shr:2
+  v += dpp_f64<0x114, 0xf>(v, 0.0);   // row_shr:4
+  v += dpp_f64<0x118, 0xf>(v, 0.0);   // row_shr:8
+  v += dpp_f64<0x142, 0xa>(v, 0.0);   // row_bcast:15 into rows 1 and 3
+  v += dpp_f64<0x143, 0xc>(v, 0.0);   // row_bcast:31 into rows 2 and 3
+  return readlane_f64(v, 63);
 }
 MK_GPU double bcast(double v, int lane) { return __shfl(v, lane); }
 MK_GPU V3 bcast3(V3 v, int lane) { return v3(__shfl(v.x, lane), __shfl(v.y, lane), __shfl(v.z, lane)); }
 
-// Wave-wide arg-min / arg-max of (key, id); ties go to the smaller id.  Every lane
-// receives the result.
+// Wave-wide arg-min / arg-max of (key, id); ties go to the smaller id (ids < 0 mean "no
+// candidate" for arg-max).  Every lane receives the result.
+struct KeyId {
+  double key;
+  int id;
+};
+MK_GPU KeyId min_of(KeyId a, KeyId b) { return (b.key < a.key || (b.key == a.key && b.id < a.id)) ? b : a; }
+MK_GPU KeyId max_of(KeyId a, KeyId b) {
+  return (b.key > a.key || (b.key == a.key && b.id >= 0 && (a.id < 0 || b.id < a.id))) ? b : a;
+}
+template <int CTRL, int ROW_MASK>
+MK_GPU KeyId dpp_keyid(KeyId v, KeyId fill) {
+  return KeyId{dpp_f64<CTRL, ROW_MASK>(v.key, fill.key), dpp_i32<CTRL, ROW_MASK>(v.id, fill.id)};
+}
+#define MK_WAVE_SCAN(v, fill, OP)                  \
+  v = OP(v, dpp_keyid<0x111, 0xf>(v, fill));       \
+  v = OP(v, dpp_keyid<0x112, 0xf>(v, fill));       \
+  v = OP(v, dpp_keyid<0x114, 0xf>(v, fill));       \
+  v = OP(v, dpp_keyid<0x118, 0xf>(v, fill));       \
+  v = OP(v, dpp_keyid<0x142, 0xa>(v, fill));       \
+  v = OP(v, dpp_keyid<0x143, 0xc>(v, fill));
 MK_GPU void wave_argmin(double& key, int& id) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double ok = __shfl_xor(key, o);
-    const int oi = __shfl_xor(id, o);
-    if (ok < key || (ok == key && oi < id)) { key = ok; id = oi; }
-  }
+  KeyId v{key, id};
+  const KeyId fill{INFINITY, 0x7fffffff};
+  MK_WAVE_SCAN(v, fill, min_of)
+  key = readlane_f64(v.key, 63);
+  id = __builtin_amdgcn_readlane(v.id, 63);
 }
 MK_GPU void wave_argmax(double& key, int& id) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double ok = __shfl_xor(key, o);
-    const int oi = __shfl_xor(id, o);
-    if (ok > key || (ok == key && oi >= 0 && (id < 0 || oi < id))) { key = ok; id = oi; }
-  }
+  KeyId v{key, id};
+  const KeyId fill{-INFINITY, -1};
+  MK_WAVE_SCAN(v, fill, max_of)
+  key = readlane_f64(v.key, 63);
+  id = __builtin_amdgcn_readlane(v.id, 63);
 }
 
 // ------------------------------------------------------------ geom distance ----
@@ -499,35 +535,36 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
     double up = 0.0;
     bool failed = false;
     for (;;) {
-      // r = (N'H^-1N)^-1 N'H^-1 n+   (lane a works on active constraint a)
+      // r = (N'H^-1N)^-1 N'H^-1 n+   (lane a works on active constraint a; values of other
+      // lanes are fetched with lane reads, the indices being wave-uniform)
       double rva = 0.0;
-      if (lane < na) {
-        const int ida = s.act[lane];
-        if (ida < 2 * n) {
-          rva = (ida < n) ? s.hin[ida] : -s.hin[ida - n];
-        } else {
-          const double* g = s.Gg + (ida - 2 * n) * np;
+      {
+        const int ida = lane < na ? s.act[lane] : 0;
+        const int jb = ida < n ? ida : (ida < 2 * n ? ida - n : 0);
+        const double hj = __shfl(hin, jb);
+        if (lane < na) {
+          if (ida < 2 * n) {
+            rva = (ida < n) ? hj : -hj;
+          } else {
+            const double* g = s.Gg + (ida - 2 * n) * np;
 #pragma unroll 4
-          for (int j = 0; j < n; ++j) rva += g[j] * s.hin[j];
+            for (int j = 0; j < n; ++j) rva += g[j] * s.hin[j];
+          }
         }
-        s.rv[lane] = rva;
       }
-      __syncthreads();
       double ra = 0.0;
-      if (lane < na) {
-        const double* mr = s.Minv + lane * na1;
-#pragma unroll 4
-        for (int b2 = 0; b2 < na; ++b2) ra += mr[b2] * s.rv[b2];
-        s.rr[lane] = ra;
+      {
+        const double* mr = s.Minv + (lane < na ? lane : 0) * na1;
+        for (int b2 = 0; b2 < na; ++b2) ra += mr[b2] * readlane_f64(rva, b2);
+        if (lane >= na) ra = 0.0;
       }
-      __syncthreads();
       // step direction in x
       double z = 0.0;
-      if (lane < n) {
-        z = hin;
-#pragma unroll 4
-        for (int a = 0; a < na; ++a) z -= s.HiN[a * np + lane] * s.rr[a];
-        z = -z;
+      {
+        double acc = hin;
+        const double* hc = s.HiN + (lane < n ? lane : 0);
+        for (int a = 0; a < na; ++a) acc -= hc[a * np] * readlane_f64(ra, a);
+        z = lane < n ? -acc : 0.0;
       }
       const double nz = -wave_sum(npl * z);
       const bool dependent = nz <= 1e-13 * nHn;
@@ -547,11 +584,16 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
         // full step: p joins the active set
         const double is = 1.0 / nz;
         if (lane < n) s.HiN[na * np + lane] = hin;
-        if (lane < na) {
-          double* mr = s.Minv + lane * na1;
-          for (int b2 = 0; b2 < na; ++b2) mr[b2] += ra * s.rr[b2] * is;
-          mr[na] = -ra * is;
-          s.Minv[na * na1 + lane] = -ra * is;
+        {
+          double* mr = s.Minv + (lane < na ? lane : 0) * na1;
+          for (int b2 = 0; b2 < na; ++b2) {
+            const double rb = readlane_f64(ra, b2);
+            if (lane < na) mr[b2] += ra * rb * is;
+          }
+          if (lane < na) {
+            mr[na] = -ra * is;
+            s.Minv[na * na1 + lane] = -ra * is;
+          }
         }
         if (lane == 0) {
           s.Minv[na * na1 + na] = is;
