@@ -461,6 +461,64 @@ bool build_dense(const HostModel& m, const mk_task_desc* tasks, int ntask, const
     }
   }
   D.n_rows = rows;
+  // flattened forms of the limits for the kernels: per-dof bounds, per-pair records
+  {
+    int ncfg = 0;
+    for (int l = 0; l < nlimit; ++l) ncfg += limits[l].type == MK_LIMIT_CONFIGURATION;
+    if (ncfg <= 1) {
+      std::vector<MkDenseDofBound> bd(m.nv);
+      for (int i = 0; i < m.nv; ++i) bd[i] = MkDenseDofBound{-INFINITY, INFINITY, 1.0, INFINITY, 0, 0};
+      for (int l = 0; l < nlimit; ++l) {
+        const mk_limit_desc& L = limits[l];
+        if (L.type == MK_LIMIT_CONFIGURATION) {
+          for (int j = 0; j < m.njnt; ++j) {
+            if (m.jnt_type[j] == MK_JNT_FREE || !m.jnt_limited[j]) continue;
+            MkDenseDofBound& b = bd[m.jnt_dofadr[j]];
+            b.lower = m.jnt_range[2 * j] + L.min_distance_from_limits;
+            b.upper = m.jnt_range[2 * j + 1] - L.min_distance_from_limits;
+            b.gain = L.gain;
+            b.qadr = m.jnt_qposadr[j];
+            b.has_cfg = 1;
+          }
+        } else if (L.type == MK_LIMIT_VELOCITY) {
+          for (int k = 0; k < L.n; ++k) bd[L.index[k]].vmax = std::min(bd[L.index[k]].vmax, L.vmax[k]);
+        }
+      }
+      if (upload(allocs, bd, &D.dof_bound) != MK_OK) { why = g_last_error; return false; }
+    }
+    std::vector<MkDensePair> pr;
+    std::vector<uint64_t> mask(m.nbody, 0);
+    for (int b = 1; b < m.nbody; ++b) {
+      mask[b] = mask[m.body_parentid[b]];
+      for (int j = m.body_jntadr[b]; j >= 0 && j < m.body_jntadr[b] + m.body_jntnum[b]; ++j) {
+        const int t = m.jnt_type[j], w = t == MK_JNT_FREE ? 6 : t == MK_JNT_BALL ? 3 : 1;
+        for (int k = 0; k < w; ++k) mask[b] |= 1ull << (m.jnt_dofadr[j] + k);
+      }
+    }
+    for (int l = 0; l < nlimit; ++l) {
+      const mk_limit_desc& L = limits[l];
+      if (L.type != MK_LIMIT_COLLISION) continue;
+      for (int k = 0; k < L.n; ++k) {
+        int g1 = L.index[2 * k], g2 = L.index[2 * k + 1];
+        MkDensePair P;
+        memset(&P, 0, sizeof(P));
+        P.swap = m.geom_type[g1] > m.geom_type[g2];
+        if (P.swap) std::swap(g1, g2);
+        P.t1 = m.geom_type[g1]; P.t2 = m.geom_type[g2];
+        P.b1 = m.geom_bodyid[g1]; P.b2 = m.geom_bodyid[g2];
+        P.row = D.limit[l].row0 + k;
+        P.mask1 = mask[P.b1]; P.mask2 = mask[P.b2];
+        memcpy(P.size1, &m.geom_size[3 * g1], 24); memcpy(P.size2, &m.geom_size[3 * g2], 24);
+        memcpy(P.pos1, &m.geom_pos[3 * g1], 24); memcpy(P.pos2, &m.geom_pos[3 * g2], 24);
+        memcpy(P.quat1, &m.geom_quat[4 * g1], 32); memcpy(P.quat2, &m.geom_quat[4 * g2], 32);
+        P.gain = L.gain; P.d_min = L.minimum_distance_from_collisions;
+        P.d_detect = L.collision_detection_distance; P.relax = L.bound_relaxation;
+        pr.push_back(P);
+      }
+    }
+    D.npairs = (int)pr.size();
+    if (!pr.empty() && upload(allocs, pr, &D.pairs) != MK_OK) { why = g_last_error; return false; }
+  }
   int npath = 0;   // total length of the root -> body paths
   for (int b = 0; b < m.nbody; ++b)
     for (int x = b; x != 0; x = m.body_parentid[x]) ++npath;

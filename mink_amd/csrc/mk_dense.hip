@@ -908,72 +908,81 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     double lo = -INFINITY, hi = INFINITY;
     double* Gb = G_out ? G_out + b * (long)mrows * n : nullptr;
     double* hb = h_out ? h_out + b * (long)mrows : nullptr;
-    int grow = 0;
-    for (int l = 0; l < prob->nlimit; ++l) {
-      const MkDenseLimit& L = prob->limit[l];
-      if (L.type == MK_LIMIT_CONFIGURATION) {
-        for (int kk = 0; kk < L.n; ++kk) {
-          const int j = L.index[kk];
-          const int dof = m.jnt_dofadr[j], qa = m.jnt_qposadr[j];
-          const double up = L.gain * (m.jnt_range[2 * j + 1] - L.min_dist - qb[qa]);
-          const double dn = L.gain * (qb[qa] - (m.jnt_range[2 * j] + L.min_dist));
-          if (lane == dof) { hi = fmin(hi, up); lo = fmax(lo, -dn); }
-          if (Gb && own) {
-            Gb[(long)(L.row0 + kk) * n + lane] = lane == dof ? 1.0 : 0.0;
-            Gb[(long)(L.row0 + L.n + kk) * n + lane] = lane == dof ? -1.0 : 0.0;
-          }
-          if (hb && lane == 0) { hb[L.row0 + kk] = up; hb[L.row0 + L.n + kk] = dn; }
-        }
-      } else if (L.type == MK_LIMIT_VELOCITY) {
-        for (int kk = 0; kk < L.n; ++kk) {
-          const int dof = L.index[kk];
-          const double vb = dt * L.vmax[kk];
-          if (lane == dof) { hi = fmin(hi, vb); lo = fmax(lo, -vb); }
-          if (Gb && own) {
-            Gb[(long)(L.row0 + kk) * n + lane] = lane == dof ? 1.0 : 0.0;
-            Gb[(long)(L.row0 + L.n + kk) * n + lane] = lane == dof ? -1.0 : 0.0;
-          }
-          if (hb && lane == 0) { hb[L.row0 + kk] = vb; hb[L.row0 + L.n + kk] = vb; }
-        }
-      } else {  // collision avoidance: one general row per geom pair
-        for (int kk = 0; kk < L.n; ++kk, ++grow) {
-          int g1 = L.index[2 * kk], g2 = L.index[2 * kk + 1];
-          const bool swap = m.geom_type[g1] > m.geom_type[g2];
-          if (swap) { const int tmp = g1; g1 = g2; g2 = tmp; }
-          const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
-          V3 p1, p2;
-          Q4 q1, q2;
-          body_pose(s, b1, p1, q1);
-          body_pose(s, b2, p2, q2);
-          const V3 x1 = p1 + mul(q2m(q1), v3(m.geom_pos[3 * g1], m.geom_pos[3 * g1 + 1], m.geom_pos[3 * g1 + 2]));
-          const V3 x2 = p2 + mul(q2m(q2), v3(m.geom_pos[3 * g2], m.geom_pos[3 * g2 + 1], m.geom_pos[3 * g2 + 2]));
-          const M3 r1 = q2m(qmul(q1, Q4{m.geom_quat[4 * g1], m.geom_quat[4 * g1 + 1], m.geom_quat[4 * g1 + 2], m.geom_quat[4 * g1 + 3]}));
-          const M3 r2 = q2m(qmul(q2, Q4{m.geom_quat[4 * g2], m.geom_quat[4 * g2 + 1], m.geom_quat[4 * g2 + 2], m.geom_quat[4 * g2 + 3]}));
-          Contact ct;
-          const bool active = geom_distance(
-              lane, m.geom_type[g1], x1, r1, v3(m.geom_size[3 * g1], m.geom_size[3 * g1 + 1], m.geom_size[3 * g1 + 2]),
-              m.geom_type[g2], x2, r2, v3(m.geom_size[3 * g2], m.geom_size[3 * g2 + 1], m.geom_size[3 * g2 + 2]),
-              L.d_detect, ct);
-          const int row = L.row0 + kk;
-          double gval = 0.0, hval = INFINITY;
-          if (active) {
-            // witness points are (on geom1, on geom2) of the *stored* pair order
-            V3 pa = ct.p1, pb = ct.p2;
-            int ba = b1, bb = b2;
-            if (swap) { pa = ct.p2; pb = ct.p1; ba = b2; bb = b1; }
-            V3 dn = pb - pa;
-            const double nn = sqrt(dot(dn, dn));
-            const V3 nrm = nn < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nn) * dn;
-            const V3 dj = dc.jp(m.body_dofmask[bb], pb) - dc.jp(m.body_dofmask[ba], pa);
-            gval = own ? -dot(nrm, dj) : 0.0;
-            hval = ct.dist > L.d_min ? L.gain * (ct.dist - L.d_min) / dt + L.relax : L.relax;
-          }
-          if (own) s.Gg[grow * np + lane] = gval;
-          if (lane == 0) s.hg[grow] = hval;
-          if (Gb && own) Gb[(long)row * n + lane] = gval;
-          if (hb && lane == 0) hb[row] = hval;
+    const MkDenseDofBound* bounds = prob->dof_bound;
+    if (bounds && !Gb && !hb) {
+      // merged bounds of the lane's own dof
+      if (own) {
+        const MkDenseDofBound bd = bounds[lane];
+        const double vb = dt * bd.vmax;
+        hi = vb;
+        lo = -vb;
+        if (bd.has_cfg) {
+          const double qv = qb[bd.qadr];
+          hi = fmin(hi, bd.gain * (bd.upper - qv));
+          lo = fmax(lo, -(bd.gain * (qv - bd.lower)));
         }
       }
+    } else {
+      for (int l = 0; l < prob->nlimit; ++l) {
+        const MkDenseLimit& L = prob->limit[l];
+        if (L.type == MK_LIMIT_CONFIGURATION) {
+          for (int kk = 0; kk < L.n; ++kk) {
+            const int j = L.index[kk];
+            const int dof = m.jnt_dofadr[j], qa = m.jnt_qposadr[j];
+            const double up = L.gain * (m.jnt_range[2 * j + 1] - L.min_dist - qb[qa]);
+            const double dn = L.gain * (qb[qa] - (m.jnt_range[2 * j] + L.min_dist));
+            if (lane == dof) { hi = fmin(hi, up); lo = fmax(lo, -dn); }
+            if (Gb && own) {
+              Gb[(long)(L.row0 + kk) * n + lane] = lane == dof ? 1.0 : 0.0;
+              Gb[(long)(L.row0 + L.n + kk) * n + lane] = lane == dof ? -1.0 : 0.0;
+            }
+            if (hb && lane == 0) { hb[L.row0 + kk] = up; hb[L.row0 + L.n + kk] = dn; }
+          }
+        } else if (L.type == MK_LIMIT_VELOCITY) {
+          for (int kk = 0; kk < L.n; ++kk) {
+            const int dof = L.index[kk];
+            const double vb = dt * L.vmax[kk];
+            if (lane == dof) { hi = fmin(hi, vb); lo = fmax(lo, -vb); }
+            if (Gb && own) {
+              Gb[(long)(L.row0 + kk) * n + lane] = lane == dof ? 1.0 : 0.0;
+              Gb[(long)(L.row0 + L.n + kk) * n + lane] = lane == dof ? -1.0 : 0.0;
+            }
+            if (hb && lane == 0) { hb[L.row0 + kk] = vb; hb[L.row0 + L.n + kk] = vb; }
+          }
+        }
+      }
+    }
+    // collision avoidance: one general row per geom pair
+    for (int kk = 0; kk < prob->npairs; ++kk) {
+      const MkDensePair& C = prob->pairs[kk];
+      V3 p1, p2;
+      Q4 q1, q2;
+      body_pose(s, C.b1, p1, q1);
+      body_pose(s, C.b2, p2, q2);
+      const V3 x1 = p1 + mul(q2m(q1), v3(C.pos1[0], C.pos1[1], C.pos1[2]));
+      const V3 x2 = p2 + mul(q2m(q2), v3(C.pos2[0], C.pos2[1], C.pos2[2]));
+      const M3 r1 = q2m(qmul(q1, Q4{C.quat1[0], C.quat1[1], C.quat1[2], C.quat1[3]}));
+      const M3 r2 = q2m(qmul(q2, Q4{C.quat2[0], C.quat2[1], C.quat2[2], C.quat2[3]}));
+      Contact ct;
+      const bool active = geom_distance(lane, C.t1, x1, r1, v3(C.size1[0], C.size1[1], C.size1[2]), C.t2, x2, r2,
+                                        v3(C.size2[0], C.size2[1], C.size2[2]), C.d_detect, ct);
+      double gval = 0.0, hval = INFINITY;
+      if (active) {
+        // witness points are (on geom1, on geom2) of the *stored* pair order
+        V3 pa = ct.p1, pb = ct.p2;
+        uint64_t ma = C.mask1, mb = C.mask2;
+        if (C.swap) { pa = ct.p2; pb = ct.p1; ma = C.mask2; mb = C.mask1; }
+        V3 dn = pb - pa;
+        const double nn = sqrt(dot(dn, dn));
+        const V3 nrm = nn < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nn) * dn;
+        const V3 dj = dc.jp(mb, pb) - dc.jp(ma, pa);
+        gval = own ? -dot(nrm, dj) : 0.0;
+        hval = ct.dist > C.d_min ? C.gain * (ct.dist - C.d_min) / dt + C.relax : C.relax;
+      }
+      if (own) s.Gg[kk * np + lane] = gval;
+      if (lane == 0) s.hg[kk] = hval;
+      if (Gb && own) Gb[(long)C.row * n + lane] = gval;
+      if (hb && lane == 0) hb[C.row] = hval;
     }
     __syncthreads();
 

@@ -51,9 +51,28 @@ struct MkDenseLimit {
   double d_min, d_detect, relax;
 };
 
+// Box bounds of one dof, merged over the ConfigurationLimit / VelocityLimit objects of the
+// problem when that is possible (at most one configuration limit): what lane i needs.
+struct MkDenseDofBound {
+  double lower, upper, gain;   // configuration limit (range already shrunk by min_distance_from_limits)
+  double vmax;                 // velocity limit, +inf when absent
+  int32_t qadr, has_cfg;
+};
+
+// One collision pair with everything the distance / Jacobian code reads, in one record
+// (geoms ordered by type; `swap` tells that the stored pair order is the other one).
+struct MkDensePair {
+  int32_t t1, t2, b1, b2, swap, row;
+  uint64_t mask1, mask2;       // ancestor-dof masks of the two bodies
+  double size1[3], size2[3], pos1[3], pos2[3], quat1[4], quat2[4];
+  double gain, d_min, d_detect, relax;
+};
+
 struct MkDenseProblem {
   int32_t ntask, nlimit, n_rows, target_stride;
-  int32_t n_general, pad;   // rows that are not +-e_i (collision pairs)
+  int32_t n_general, npairs;   // rows that are not +-e_i (collision pairs)
+  const MkDenseDofBound* dof_bound;   // [nv], or null when the limits do not merge
+  const MkDensePair* pairs;           // [npairs], in row order
   MkDenseTask task[MK_DENSE_MAX_TASKS];
   MkDenseLimit limit[MK_DENSE_MAX_LIMITS];
 };
