@@ -959,13 +959,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       Q4 q1, q2;
       body_pose(s, C.b1, p1, q1);
       body_pose(s, C.b2, p2, q2);
-      const V3 x1 = p1 + mul(q2m(q1), v3(C.pos1[0], C.pos1[1], C.pos1[2]));
-      const V3 x2 = p2 + mul(q2m(q2), v3(C.pos2[0], C.pos2[1], C.pos2[2]));
+      const V3 x1 = p1 + qrot(q1, v3(C.pos1[0], C.pos1[1], C.pos1[2]));
+      const V3 x2 = p2 + qrot(q2, v3(C.pos2[0], C.pos2[1], C.pos2[2]));
+      const V3 sz1 = v3(C.size1[0], C.size1[1], C.size1[2]), sz2 = v3(C.size2[0], C.size2[1], C.size2[2]);
       const M3 r1 = q2m(qmul(q1, Q4{C.quat1[0], C.quat1[1], C.quat1[2], C.quat1[3]}));
-      const M3 r2 = q2m(qmul(q2, Q4{C.quat2[0], C.quat2[1], C.quat2[2], C.quat2[3]}));
+      // cheap lower bound of the distance from bounding spheres: most pairs are far apart
+      const double rad2 = C.t2 == GEOM_SPHERE ? sz2.x : sqrt(dot(sz2, sz2));
+      double lower;
+      if (C.t1 == GEOM_PLANE) {
+        lower = dot(x2 - x1, col(r1, 2)) - rad2;
+      } else {
+        const double rad1 = C.t1 == GEOM_SPHERE ? sz1.x : sqrt(dot(sz1, sz1));
+        const V3 dd = x2 - x1;
+        lower = sqrt(dot(dd, dd)) - rad1 - rad2;
+      }
       Contact ct;
-      const bool active = geom_distance(lane, C.t1, x1, r1, v3(C.size1[0], C.size1[1], C.size1[2]), C.t2, x2, r2,
-                                        v3(C.size2[0], C.size2[1], C.size2[2]), C.d_detect, ct);
+      bool active = false;
+      if (lower < C.d_detect) {
+        const M3 r2 = q2m(qmul(q2, Q4{C.quat2[0], C.quat2[1], C.quat2[2], C.quat2[3]}));
+        active = geom_distance(lane, C.t1, x1, r1, sz1, C.t2, x2, r2, sz2, C.d_detect, ct);
+      }
       double gval = 0.0, hval = INFINITY;
       if (active) {
         // witness points are (on geom1, on geom2) of the *stored* pair order
