@@ -201,6 +201,30 @@ def main():
             res["roofline"]["traffic_note"] = tj.get("note")
         if n_gpus == 1 and not args.no_extra:
             extra = {}
+            # benchmark config 1: one problem, Frame+Posture with the default ConfigurationLimit: latency of one
+            # solve_ik step and of the callers' <=20-step loop, launch + completion, inputs on the device
+            p1 = DeviceProblem(dm, W.task_specs(model, False), W.limit_specs(model, False))
+            q1, t1 = q0[:1].clone(), targets[:1].contiguous()
+            v1 = torch.empty((1, model.nv), dtype=torch.float64, device=device)
+            s1 = torch.empty(1, dtype=torch.int32, device=device)
+
+            def lat(fn, n=200):
+                for _ in range(20):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                    torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n
+
+            o1 = dict(iters=torch.empty(1, dtype=torch.int32, device=device),
+                      err=torch.empty((1, 6), dtype=torch.float64, device=device),
+                      status=torch.empty(1, dtype=torch.int32, device=device))
+            extra["config1_B1_latency"] = {
+                "solve_ik_step_us": 1e6 * lat(lambda: p1.solve(q1, t1, W.DT, W.DAMPING, v=v1, status=s1)),
+                "loop20_us": 1e6 * lat(lambda: (q1.copy_(q0[:1]), p1.iterate_(q1, t1, W.DT, W.DAMPING, 20, 1e-4, 1e-4, out=o1))),
+                "note": "wall time per call incl. launch and synchronisation; the loop is one launch of up to 20 solves"}
             # benchmark config 2: 4096 problems, Frame+Posture+Damping, Cfg+Vel limits, one solve_ik step
             p2 = DeviceProblem(dm, W.task_specs(model, True), W.limit_specs(model, True))
             v = torch.empty((4096, model.nv), dtype=torch.float64, device=device)
