@@ -427,6 +427,14 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
   asm volatile("" ::: "memory");
   int status = box_qp<NC>(HView{hstore, hstride}, c, lo, hi, x, act, upper, warm);
 #endif
+  {
+    // non-finite chain q or target: the task error, hence every entry of c, is NaN
+    if (!(fabs(diag + c[0]) < INFINITY)) {
+      status = 3;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) x[i] = 0.0;
+    }
+  }
 
   // ---- dofs outside the chain: diagonal Hessian, box limits -> clamp ----
   // (the constants of the next dof are fetched while the current one is computed)

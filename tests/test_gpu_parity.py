@@ -233,6 +233,14 @@ def test_infeasible_and_bad_arguments(env):
     tg = dm.frame_pose(dev(q), 2, 0)
     v, st = prob.solve(dev(q), tg, W.DT, W.DAMPING)
     assert st.cpu().tolist() == [0, 2, 0]
+    qn = q.copy()
+    qn[2, 5] = np.nan                       # non-finite input: reported, velocity zeroed on the chain
+    v, st = prob.solve(dev(qn), tg, W.DT, W.DAMPING)
+    assert st.cpu().tolist() == [0, 2, 3]
+    tn = tg.clone()
+    tn[0, 4] = float("inf")
+    v, st = prob.solve(dev(q), tn, W.DT, W.DAMPING)
+    assert st.cpu().tolist() == [3, 2, 0]
     with pytest.raises(L.MinkAmdError):
         prob.solve(dev(q), tg, -1.0, W.DAMPING)
     with pytest.raises(ValueError):
