@@ -20,6 +20,7 @@ _GPU_NAMES = {
     "build_ik": "solve_ik", "solve_ik": "solve_ik", "solve_ik_iterate": "solve_ik", "Problem": "solve_ik",
     "custom_configuration_vector": "utils", "get_freejoint_dims": "utils", "get_body_geom_ids": "utils",
     "get_subtree_body_ids": "utils", "get_subtree_geom_ids": "utils", "get_body_body_ids": "utils",
+    "move_mocap_to_frame": "utils",
     "move_to": "rollout", "LinearWaypointReach": "rollout", "LinearWaypointReachConfig": "rollout",
 }
 

@@ -34,6 +34,31 @@ def device_model(model: Model, device) -> DeviceModel:
     return dm
 
 
+class MocapData:
+    """The part of ``mujoco.MjData`` the reference's callers touch next to the IK path: the
+    poses of the mocap bodies that carry teleoperation targets
+    (interactive_scripts/teleop_mouse.py:88-99, mink/utils.py:10-35, mink/lie/se3.py:77-91).
+    ``mocap_pos`` [.., nmocap, 3] and ``mocap_quat`` [.., nmocap, 4] (wxyz) are numpy arrays
+    for a single configuration and device tensors with a leading batch axis otherwise."""
+
+    def __init__(self, configuration: "Configuration"):
+        self.configuration = configuration
+        self.reset()
+
+    def reset(self) -> None:
+        cfg, m = self.configuration, self.configuration.model
+        ids = [b for b in range(m.nbody) if m.body_mocapid[b] >= 0]
+        ids.sort(key=lambda b: m.body_mocapid[b])
+        pos = np.array([m.body_pos[b] for b in ids], dtype=np.float64).reshape(len(ids), 3)
+        quat = np.array([m.body_quat[b] for b in ids], dtype=np.float64).reshape(len(ids), 4)
+        if cfg.batched:
+            B = cfg.batch_size
+            self.mocap_pos = torch.tensor(pos, device=cfg.device).repeat(B, 1, 1)
+            self.mocap_quat = torch.tensor(quat, device=cfg.device).repeat(B, 1, 1)
+        else:
+            self.mocap_pos, self.mocap_quat = pos, quat
+
+
 class Configuration:
     def __init__(self, model: Model, q=None, device="cuda:0"):
         self.model = model
@@ -42,6 +67,7 @@ class Configuration:
         self.batched = False
         self._q = torch.tensor(model.qpos0[None, :], dtype=torch.float64, device=self.device)
         self.update(q)
+        self.data = MocapData(self)
 
     # ---- state -------------------------------------------------------------
     def update(self, q=None) -> None:
@@ -49,6 +75,7 @@ class Configuration:
         unlike the reference there is no FK cache to refresh."""
         if q is None:
             return
+        prev = (self.batched, self._q.shape[0])
         if isinstance(q, torch.Tensor):
             t = q.detach().to(device=self.device, dtype=torch.float64)
         else:
@@ -63,6 +90,8 @@ class Configuration:
         if t.shape[1] != self.model.nq:
             raise ValueError(f"q must have {self.model.nq} entries per configuration, got {t.shape[1]}")
         self._q = t.contiguous().clone()
+        if hasattr(self, "data") and prev != (self.batched, self._q.shape[0]):
+            self.data.reset()   # the mocap arrays follow the batch shape
 
     def update_from_keyframe(self, key_name: str) -> None:
         key_id = self.model.key_id(key_name)

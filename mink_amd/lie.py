@@ -319,6 +319,19 @@ class SE3(MatrixLieGroup):
         return cls.from_rotation_and_translation(SO3.from_matrix(m[..., :3, :3]), m[..., :3, 3])
 
     @classmethod
+    def from_mocap_id(cls, data, mocap_id: int):
+        """Pose of a mocap body held by ``configuration.data`` (mink/lie/se3.py:77-82)."""
+        data = getattr(data, "data", data)
+        return cls.from_rotation_and_translation(SO3(data.mocap_quat[..., mocap_id, :]),
+                                                 data.mocap_pos[..., mocap_id, :])
+
+    @classmethod
+    def from_mocap_name(cls, model, data, mocap_name: str):
+        """mink/lie/se3.py:84-91."""
+        from .utils import _mocap_id
+        return cls.from_mocap_id(data, _mocap_id(model, mocap_name))
+
+    @classmethod
     def sample_uniform(cls, batch=(), generator=None, device=None):
         t = 2 * torch.rand(*batch, 3, dtype=torch.float64, generator=generator, device=device) - 1
         return cls.from_rotation_and_translation(SO3.sample_uniform(batch, generator, device), t)

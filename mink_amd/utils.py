@@ -6,8 +6,31 @@ from typing import Optional
 import numpy as np
 
 from . import constants as consts
-from .exceptions import InvalidKeyframe
+from .exceptions import InvalidKeyframe, InvalidMocapBody
 from .mjcf import JNT_FREE
+
+
+def _mocap_id(model, mocap_name: str) -> int:
+    bid = model.body_id(mocap_name)
+    mocap_id = int(model.body_mocapid[bid]) if bid >= 0 else -1
+    if mocap_id == -1:
+        raise InvalidMocapBody(mocap_name, model)
+    return mocap_id
+
+
+def move_mocap_to_frame(model, data, mocap_name: str, frame_name: str, frame_type: str) -> None:
+    """Put a mocap body at the pose of a frame (mink/utils.py:10-35).  ``data`` is the
+    ``.data`` of a :class:`Configuration` (or the configuration itself), which is where the
+    frame pose comes from."""
+    mocap_id = _mocap_id(model, mocap_name)
+    data = getattr(data, "data", data)
+    T = data.configuration.get_transform_frame_to_world(frame_name, frame_type)
+    if data.configuration.batched:
+        data.mocap_pos[:, mocap_id] = T.translation()
+        data.mocap_quat[:, mocap_id] = T.rotation().wxyz
+    else:
+        data.mocap_pos[mocap_id] = T.translation().cpu().numpy()
+        data.mocap_quat[mocap_id] = T.rotation().wxyz.cpu().numpy()
 
 
 def get_freejoint_dims(model):

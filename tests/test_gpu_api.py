@@ -201,3 +201,30 @@ def test_errors_and_limit_check(model, golden_dir):
         mink.solve_ik(cfg, [frame], 0.005, "osqp", 1e-3)
     cfg.update_from_keyframe("home")
     np.testing.assert_array_equal(cfg.q, model.key_qpos[model.key_id("home")])
+
+
+def test_mocap_target_ingestion(model):
+    """teleop_mouse.py:88-99: the mocap body starts at the end-effector, the task target is read from it."""
+    cfg = mink.Configuration(model)
+    cfg.update_from_keyframe("home")
+    assert cfg.data.mocap_pos.shape == (1, 3)
+    mink.move_mocap_to_frame(model, cfg.data, "pinch_site_target", "pinch_site", "site")
+    T = mink.SE3.from_mocap_name(model, cfg.data, "pinch_site_target")
+    ref = cfg.get_transform_frame_to_world("pinch_site", "site")
+    same_pose(T.wxyz_xyz.numpy(), ref.wxyz_xyz.numpy(), 1e-15)
+    frame = mink.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0)
+    frame.set_target(T)
+    np.testing.assert_allclose(frame.compute_error(cfg), 0.0, atol=1e-12)
+    cfg.data.mocap_pos[0] += np.array([0.05, 0.0, -0.02])          # the user drags the target
+    frame.set_target(mink.SE3.from_mocap_name(model, cfg.data, "pinch_site_target"))
+    assert np.linalg.norm(frame.compute_error(cfg)[:3]) == pytest.approx(np.linalg.norm([0.05, 0.0, -0.02]), abs=1e-12)
+    with pytest.raises(mink.InvalidMocapBody):
+        mink.move_mocap_to_frame(model, cfg.data, "base_link", "pinch_site", "site")
+    # batched: one mocap pose per configuration
+    rng = np.random.default_rng(0)
+    from mink_amd import workloads as W
+    bcfg = mink.Configuration(model, W.sample_q(model, rng, 5))
+    assert tuple(bcfg.data.mocap_pos.shape) == (5, 1, 3)
+    mink.move_mocap_to_frame(model, bcfg, "pinch_site_target", "pinch_site", "site")
+    Tb = mink.SE3.from_mocap_name(model, bcfg.data, "pinch_site_target")
+    same_pose(Tb.wxyz_xyz.cpu().numpy(), bcfg.get_transform_frame_to_world("pinch_site", "site").wxyz_xyz.cpu().numpy(), 1e-15)
