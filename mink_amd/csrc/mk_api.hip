@@ -447,8 +447,10 @@ bool build_dense(const HostModel& m, const mk_task_desc* tasks, int ntask, const
         if (g1 < 0 || g1 >= m.ngeom || g2 < 0 || g2 >= m.ngeom) { why = "geom id out of range"; return false; }
         int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
         if (t1 > t2) std::swap(t1, t2);
-        const bool ok = (t1 == 0 && (t2 == 6 || t2 == 2)) || (t1 == 2 && t2 == 2) || (t1 == 6 && t2 == 6);
-        if (!ok) { why = "geom pair types without a distance routine (supported: plane-box, plane-sphere, sphere-sphere, box-box)"; return false; }
+        // MuJoCo geom types: plane 0, sphere 2, capsule 3, box 6
+        const bool ok = (t1 == 0 && (t2 == 2 || t2 == 3 || t2 == 6)) || (t1 == 2 && (t2 == 2 || t2 == 3 || t2 == 6)) ||
+                        (t1 == 3 && t2 == 3) || (t1 == 6 && t2 == 6);
+        if (!ok) { why = "geom pair types without a distance routine (supported: plane-{sphere,capsule,box}, sphere-{sphere,capsule,box}, capsule-capsule, box-box)"; return false; }
       }
       O.n = L.n;
       O.gain = L.gain;

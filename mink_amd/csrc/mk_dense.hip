@@ -12,7 +12,8 @@
 //   3. P = damping I + sum_t (Jw'Jw + mu I), c = -sum_t ew'Jw  (mink/solve_ik.py:13-22),
 //      row i of P accumulated by lane i in LDS;
 //   4. limits: ConfigurationLimit / VelocityLimit rows are +-e_i, kept as two bounds per
-//      lane; CollisionAvoidanceLimit rows are general rows in LDS, with the box-box
+//      lane; CollisionAvoidanceLimit rows (plane / sphere / capsule / box primitives) are
+//      general rows in LDS, with the box-box
 //      closest-feature search spread over the lanes (mink/solve_ik.py:25-40);
 //   5. the Goldfarb-Idnani dual active-set method (the algorithm of the reference's QP
 //      backend, quadprog), v = dq / dt.
@@ -28,7 +29,7 @@ namespace {
 
 #define MK_GPU __device__ __forceinline__
 
-constexpr int GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_BOX = 6;
+constexpr int GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_BOX = 6;
 
 // Wave-wide reductions with DPP lane moves (row shifts inside the 16-lane rows, then the
 // two row broadcasts): ALU speed, where shuffles through the LDS crossbar cost an LDS
@@ -263,6 +264,57 @@ MK_GPU bool geom_distance(int lane, int t1, V3 c1, const M3& r1, V3 s1, int t2, 
     ct.dist = nrm - s1.x - s2.x;
     ct.p1 = c1 + s1.x * ax;
     ct.p2 = c2 - s2.x * ax;
+  } else if (t1 == GEOM_PLANE && t2 == GEOM_CAPSULE) {
+    // the lower of the two end spheres (capsule: size = radius, half-length along its z axis)
+    const V3 n = col(r1, 2), ax = col(r2, 2);
+    const V3 ea = c2 + s2.y * ax, eb = c2 - s2.y * ax;
+    const double da = dot(ea - c1, n) - s2.x, db = dot(eb - c1, n) - s2.x;
+    const V3 e = da <= db ? ea : eb;
+    ct.dist = da <= db ? da : db;
+    ct.p2 = e - s2.x * n;
+    ct.p1 = ct.p2 - ct.dist * n;
+  } else if ((t1 == GEOM_SPHERE || t1 == GEOM_CAPSULE) && t2 == GEOM_CAPSULE) {
+    // closest points of the axis segments (a sphere is a segment of length 0), then two spheres
+    const V3 a2 = col(r2, 2);
+    V3 u = c1, w;
+    if (t1 == GEOM_SPHERE) {
+      const double t = fmin(fmax(dot(c1 - c2, a2), -s2.y), s2.y);
+      w = c2 + t * a2;
+    } else {
+      const V3 a1 = col(r1, 2);
+      seg_seg(c1 - s1.y * a1, c1 + s1.y * a1, c2 - s2.y * a2, c2 + s2.y * a2, u, w);
+    }
+    V3 d = w - u;
+    double nrm = sqrt(dot(d, d));
+    V3 ax = nrm < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nrm) * d;
+    if (nrm < MK_MINVAL) nrm = 0.0;
+    ct.dist = nrm - s1.x - s2.x;
+    ct.p1 = u + s1.x * ax;
+    ct.p2 = w - s2.x * ax;
+  } else if (t1 == GEOM_SPHERE && t2 == GEOM_BOX) {
+    const V3 loc = mulT(r2, c1 - c2);
+    const V3 cl = v3(fmin(fmax(loc.x, -s2.x), s2.x), fmin(fmax(loc.y, -s2.y), s2.y), fmin(fmax(loc.z, -s2.z), s2.z));
+    if (fabs(loc.x) > s2.x || fabs(loc.y) > s2.y || fabs(loc.z) > s2.z) {   // centre outside the box
+      const V3 pb = c2 + mul(r2, cl);
+      V3 d = c1 - pb;
+      double nrm = sqrt(dot(d, d));
+      V3 ax = nrm < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nrm) * d;
+      if (nrm < MK_MINVAL) nrm = 0.0;
+      ct.dist = nrm - s1.x;
+      ct.p1 = c1 - s1.x * ax;
+      ct.p2 = pb;
+    } else {   // centre inside: leave through the nearest face
+      const double gx = s2.x - fabs(loc.x), gy = s2.y - fabs(loc.y), gz = s2.z - fabs(loc.z);
+      const int k = (gx <= gy && gx <= gz) ? 0 : (gy <= gz ? 1 : 2);
+      const double lk = comp(loc, k), gk = k == 0 ? gx : (k == 1 ? gy : gz);
+      const double sgn = lk >= 0.0 ? 1.0 : -1.0;
+      const V3 ax = sgn * col(r2, k);
+      V3 face = loc;
+      if (k == 0) face.x = sgn * s2.x; else if (k == 1) face.y = sgn * s2.y; else face.z = sgn * s2.z;
+      ct.dist = -gk - s1.x;
+      ct.p2 = c2 + mul(r2, face);
+      ct.p1 = c1 - s1.x * ax;
+    }
   } else {  // box - box
     // bounding spheres first: most pairs are far apart
     const V3 d = c2 - c1;
@@ -964,12 +1016,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       const V3 sz1 = v3(C.size1[0], C.size1[1], C.size1[2]), sz2 = v3(C.size2[0], C.size2[1], C.size2[2]);
       const M3 r1 = q2m(qmul(q1, Q4{C.quat1[0], C.quat1[1], C.quat1[2], C.quat1[3]}));
       // cheap lower bound of the distance from bounding spheres: most pairs are far apart
-      const double rad2 = C.t2 == GEOM_SPHERE ? sz2.x : sqrt(dot(sz2, sz2));
+      const double rad2 = C.t2 == GEOM_SPHERE ? sz2.x : (C.t2 == GEOM_CAPSULE ? sz2.x + sz2.y : sqrt(dot(sz2, sz2)));
       double lower;
       if (C.t1 == GEOM_PLANE) {
         lower = dot(x2 - x1, col(r1, 2)) - rad2;
       } else {
-        const double rad1 = C.t1 == GEOM_SPHERE ? sz1.x : sqrt(dot(sz1, sz1));
+        const double rad1 = C.t1 == GEOM_SPHERE ? sz1.x : (C.t1 == GEOM_CAPSULE ? sz1.x + sz1.y : sqrt(dot(sz1, sz1)));
         const V3 dd = x2 - x1;
         lower = sqrt(dot(dd, dd)) - rad1 - rad2;
       }

@@ -439,10 +439,16 @@ def _closest_box_box(c1, r1, h1, c2, r2, h2):
     return math.sqrt(best), p1, p2
 
 
+def _sphere_sphere(c1, r1, c2, r2):
+    axis, nrm = mju_normalize3(c2 - c1)
+    return nrm - r1 - r2, c1 + r1 * axis, c2 - r2 * axis
+
+
 def mj_geomDistance(m, d, g1, g2, distmax):
     """Smallest signed distance between two primitive geoms, and the segment
     (fromto) joining the closest points, or (distmax, zeros) when farther than
-    distmax.  Supported pairs: plane-box, box-box (separated), sphere-*.
+    distmax.  Supported pairs: plane-{sphere, capsule, box}, sphere-{sphere, capsule, box},
+    capsule-capsule, box-box.
     PARITY UNPINNED: MuJoCo's box-box routine is not restated; the Euclidean
     closest-point distance is used instead."""
     t1, t2 = m.geom_type[g1], m.geom_type[g2]
@@ -472,6 +478,41 @@ def mj_geomDistance(m, d, g1, g2, distmax):
         dist = nrm - s1[0] - s2[0]
         p1 = c1 + s1[0] * axis
         p2 = c2 - s2[0] * axis
+    elif t1 == GEOM_PLANE and t2 == GEOM_CAPSULE:
+        # the lower of the two end spheres (mjc_PlaneCapsule makes one contact per end)
+        n, ax = r1[:, 2], r2[:, 2]
+        ends = [c2 + ax * s2[1], c2 - ax * s2[1]]
+        depth = [float((e - c1) @ n) - s2[0] for e in ends]
+        k = 0 if depth[0] <= depth[1] else 1
+        dist = depth[k]
+        p2 = ends[k] - s2[0] * n
+        p1 = p2 - dist * n
+    elif t1 == GEOM_SPHERE and t2 == GEOM_CAPSULE:
+        ax = r2[:, 2]
+        t = float(np.clip((c1 - c2) @ ax, -s2[1], s2[1]))
+        dist, p1, p2 = _sphere_sphere(c1, s1[0], c2 + t * ax, s2[0])
+    elif t1 == GEOM_CAPSULE and t2 == GEOM_CAPSULE:
+        a1, a2 = r1[:, 2], r2[:, 2]
+        u, w = _seg_seg(c1 - a1 * s1[1], c1 + a1 * s1[1], c2 - a2 * s2[1], c2 + a2 * s2[1])
+        dist, p1, p2 = _sphere_sphere(u, s1[0], w, s2[0])
+    elif t1 == GEOM_SPHERE and t2 == GEOM_BOX:
+        loc = r2.T @ (c1 - c2)
+        clamped = np.clip(loc, -s2, s2)
+        if np.any(np.abs(loc) > s2):          # centre outside the box
+            pb = c2 + r2 @ clamped
+            axis, nrm = mju_normalize3(c1 - pb)
+            dist = nrm - s1[0]
+            p1, p2 = c1 - s1[0] * axis, pb
+        else:                                 # centre inside: leave through the nearest face
+            gap = s2 - np.abs(loc)
+            k = int(np.argmin(gap))
+            sgn = 1.0 if loc[k] >= 0 else -1.0
+            axis = r2[:, k] * sgn
+            dist = -float(gap[k]) - s1[0]
+            face = loc.copy()
+            face[k] = sgn * s2[k]
+            p2 = c2 + r2 @ face
+            p1 = c1 - s1[0] * axis
     elif t1 == GEOM_BOX and t2 == GEOM_BOX:
         dist, p1, p2 = _closest_box_box(c1, r1, s1, c2, r2, s2)
     else:

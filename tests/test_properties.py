@@ -244,3 +244,85 @@ def test_gpu_floating_base_tree_vs_oracle(fmodel):
         ref = q[b].copy()
         mj.mj_integratePos(fmodel, ref, vv[b], 0.02)
         np.testing.assert_allclose(qi[b].cpu().numpy(), ref, rtol=0, atol=1e-14)
+
+
+PRIM_PAIRS = [("obj_geom", "shin_geom"), ("shin_geom", "bar_geom"), ("ground", "shin_geom"), ("obj_geom", "torso_geom"),
+              ("obj_geom", "fore_geom"), ("leg_geom", "obj_geom"), ("ground", "fore_geom"), ("torso_geom", "fore_geom"),
+              ("upper_geom", "bar_geom"), ("ground", "obj_geom")]
+
+
+def near_configuration(model, rng, pair):
+    """A random configuration with the free object moved next to one geom of `pair`."""
+    q = random_q(model, rng)
+    if "obj_geom" in pair:
+        other = pair[0] if pair[1] == "obj_geom" else pair[1]
+        cfg = o.Configuration(model, q)
+        c = cfg.data.geom_xpos[model.geom_id(other)]
+        d = rng.normal(size=3)
+        a = model.jnt_qposadr[model.joint_id("obj_free")]
+        q[a:a + 3] = c + d / np.linalg.norm(d) * rng.uniform(0.0, 0.25)
+    return q
+
+
+@pytest.mark.parametrize("pair", PRIM_PAIRS)
+def test_primitive_distance_gradient_matches_contact_row(fmodel, pair):
+    """d(dist)/dq by finite differences equals n'(Jp2 - Jp1) at the witness points: checks
+    distance, witness points and the normal of every primitive routine together."""
+    rng = np.random.default_rng(abs(hash(pair)) % 1000)
+    g1, g2 = fmodel.geom_id(pair[0]), fmodel.geom_id(pair[1])
+    eps, checked = 1e-7, 0
+    for _ in range(12):
+        q = near_configuration(fmodel, rng, pair)
+        cfg = o.Configuration(fmodel, q)
+        d0, fromto = mj.mj_geomDistance(fmodel, cfg.data, g1, g2, 10.0)
+        if abs(d0) < 1e-3:
+            continue
+        nrm = fromto[3:] - fromto[:3]
+        nrm = nrm / np.linalg.norm(nrm)
+        j1 = mj.mj_jac(fmodel, cfg.data, fromto[:3], fmodel.geom_bodyid[g1])[0]
+        j2 = mj.mj_jac(fmodel, cfg.data, fromto[3:], fmodel.geom_bodyid[g2])[0]
+        row = nrm @ (j2 - j1)
+        if d0 < 0:
+            row = -row       # fromto points from geom1 to geom2 also when they overlap; the distance then grows the other way
+        grad = np.zeros(fmodel.nv)
+        for i in range(fmodel.nv):
+            dv = np.zeros(fmodel.nv)
+            dv[i] = 1.0
+            qp, qm = q.copy(), q.copy()
+            mj.mj_integratePos(fmodel, qp, dv, eps)
+            mj.mj_integratePos(fmodel, qm, dv, -eps)
+            dp, _ = mj.mj_geomDistance(fmodel, o.Configuration(fmodel, qp).data, g1, g2, 10.0)
+            dm, _ = mj.mj_geomDistance(fmodel, o.Configuration(fmodel, qm).data, g1, g2, 10.0)
+            grad[i] = (dp - dm) / (2 * eps)
+        if pair == ("torso_geom", "fore_geom") and d0 < 0:
+            continue         # overlapping boxes report a penetration depth, not a smooth distance
+        np.testing.assert_allclose(row, grad, rtol=0, atol=2e-5)
+        checked += 1
+    assert checked >= 3
+
+
+@pytest.mark.gpu
+def test_gpu_primitive_collision_rows_vs_oracle(fmodel):
+    import torch
+    from mink_amd.engine import DeviceModel, DeviceProblem
+    dm = DeviceModel(fmodel, "cuda:0")
+    rng = np.random.default_rng(11)
+    pairs = [(fmodel.geom_id(a), fmodel.geom_id(b)) for a, b in PRIM_PAIRS]
+    spec = dict(type=L.LIMIT_COLLISION, index=np.array(pairs, dtype=np.int32).reshape(-1), gain=0.85,
+                minimum_distance_from_collisions=0.005, collision_detection_distance=0.3, bound_relaxation=0.01)
+    prob = DeviceProblem(dm, [], [spec])
+    qs = np.array([near_configuration(fmodel, rng, PRIM_PAIRS[k % len(PRIM_PAIRS)]) for k in range(60)])
+    P, c, G, h = prob.build_qp(torch.tensor(qs, device="cuda:0"), None, 0.01, 1e-3)
+    G, h = G.cpu().numpy(), h.cpu().numpy()
+    lim = o.CollisionAvoidanceLimit(fmodel, [], gain=0.85, minimum_distance_from_collisions=0.005,
+                                    collision_detection_distance=0.3, bound_relaxation=0.01)
+    lim.geom_id_pairs = [(min(a, b), max(a, b)) for a, b in pairs]
+    active = 0
+    for b in range(len(qs)):
+        Go, ho = lim.inequalities(o.Configuration(fmodel, qs[b]), 0.01)
+        fin = np.isfinite(ho)
+        np.testing.assert_array_equal(np.isfinite(h[b]), fin)
+        np.testing.assert_allclose(h[b][fin], ho[fin], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(G[b], Go, rtol=0, atol=1e-9)
+        active += int(fin.sum())
+    assert active > 100
