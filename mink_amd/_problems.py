@@ -11,6 +11,9 @@ from .engine import DeviceProblem
 
 
 def _signature(spec: dict) -> tuple:
+    """Hashable value of a descriptor; the default ``_key`` of tasks and limits."""
+    if spec is None:
+        return None
     out = []
     for k in sorted(spec):
         v = spec[k]
@@ -22,17 +25,24 @@ def get_problem(configuration, tasks: Sequence, limits: Sequence):
     """(device problem, targets tensor) for a task / limit set; problems are cached per
     uploaded model by the value of their descriptors."""
     model = configuration.model
-    task_specs = [t._spec(model) for t in tasks]
-    limit_specs = [s for s in (l._spec(model) for l in limits) if s is not None]
-    # targets first: a missing target is reported before any device work
+    # keys (and with them missing posture targets) and targets first: a missing target
+    # is reported before any device work
+    key = (tuple(t._key(model) for t in tasks),
+           tuple(k for k in (l._key(model) for l in limits) if k is not None))
     parts = [t._target_tensor(configuration) for t in tasks if t._target_width() > 0]
-    targets = torch.cat(parts, dim=1).contiguous() if parts else None
-    key = (tuple(_signature(s) for s in task_specs), tuple(_signature(s) for s in limit_specs))
+    if not parts:
+        targets = None
+    elif len(parts) == 1:
+        targets = parts[0] if parts[0].is_contiguous() else parts[0].contiguous()
+    else:
+        targets = torch.cat(parts, dim=1).contiguous()
     cache = configuration.dmodel.problem_cache
     prob = cache.get(key)
     if prob is None:
         if len(cache) > 64:
             cache.clear()
+        task_specs = [t._spec(model) for t in tasks]
+        limit_specs = [s for s in (l._spec(model) for l in limits) if s is not None]
         prob = DeviceProblem(configuration.dmodel, task_specs, limit_specs)
         cache[key] = prob
     return prob, targets

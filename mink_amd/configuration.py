@@ -133,13 +133,15 @@ class Configuration:
         if bad.numel() == 0:
             return
         b = int(bad[0, 0])
-        jnt = int(first[b])
+        self._report_limit_violation(b, int(first[b]), bad.shape[0], safety_break)
+
+    def _report_limit_violation(self, b: int, jnt: int, n_bad: int, safety_break: bool) -> None:
         qval = float(self._q[b, self.model.jnt_qposadr[jnt]])
         qmin, qmax = (float(x) for x in self.model.jnt_range[jnt])
         if safety_break:
             raise exceptions.NotWithinConfigurationLimits(joint_id=jnt, value=qval, lower=qmin, upper=qmax,
                                                           model=self.model)
-        extra = f" (configuration {b}; {bad.shape[0]} of {self.batch_size} configurations violate limits)" \
+        extra = f" (configuration {b}; {n_bad} of {self.batch_size} configurations violate limits)" \
             if self.batched else ""
         logging.warning(f"Value {qval:.2f} at index {jnt} is outside of its limits: [{qmin:.2f}, {qmax:.2f}]{extra}")
 

@@ -133,6 +133,50 @@ class DeviceProblem:
                                                _stream_ptr(self.device)))
         return v, status
 
+    def _single_buffer(self, n_f64: int) -> torch.Tensor:
+        """Device staging of the single-configuration calls: n_f64 doubles followed by one
+        double's worth of int32 (two of them), so that one copy brings everything back."""
+        buf = getattr(self, "_single", None)
+        if buf is None or buf.numel() != n_f64 + 1:
+            buf = torch.zeros((n_f64 + 1,), dtype=torch.float64, device=self.device)
+            self._single = buf
+        return buf
+
+    def solve_single(self, q: torch.Tensor, targets: Optional[torch.Tensor], dt: float, damping: float, tol: float):
+        """Limit check + solve of ONE configuration with a single device-to-host copy (the
+        interactive callers' per-step path). Returns (v [nv] numpy, status, first offending
+        joint or -1)."""
+        _check_tensor(q, (1, self.nq), torch.float64, "q")
+        nv = self.nv
+        buf = self._single_buffer(nv)
+        base = buf.data_ptr()
+        with torch.cuda.device(self.device):
+            stream = _stream_ptr(self.device)
+            L.check(self.lib.mk_check_limits_batch(self.dmodel.handle, q.data_ptr(), float(tol), 1,
+                                                   base + 8 * nv + 4, stream))
+            L.check(self.lib.mk_solve_ik_batch(self.handle, q.data_ptr(), self._targets_ptr(targets, 1), float(dt),
+                                               float(damping), 1, base, base + 8 * nv, stream))
+        host = buf.cpu().numpy()
+        flags = host[nv:].view(np.int32)
+        return host[:nv], int(flags[0]), int(flags[1])
+
+    def iterate_single_(self, q: torch.Tensor, targets: Optional[torch.Tensor], dt: float, damping: float,
+                        max_iters: int, pos_tol: float, ori_tol: float) -> dict:
+        """`iterate_` for ONE configuration, results as numpy / ints from a single copy."""
+        _check_tensor(q, (1, self.nq), torch.float64, "q")
+        nv = self.nv
+        buf = self._single_buffer(nv + 6)
+        base = buf.data_ptr()
+        ints = base + 8 * (nv + 6)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.mk_solve_ik_iterate_batch(
+                self.handle, q.data_ptr(), self._targets_ptr(targets, 1), float(dt), float(damping), 1,
+                int(max_iters), float(pos_tol), float(ori_tol), base, ints, base + 8 * nv, ints + 4,
+                _stream_ptr(self.device)))
+        host = buf.cpu().numpy()
+        flags = host[nv + 6:].view(np.int32)
+        return dict(iters=int(flags[0]), err=host[nv:nv + 6], status=int(flags[1]), v=host[:nv])
+
     def build_qp(self, q: torch.Tensor, targets: Optional[torch.Tensor], dt: float, damping: float):
         """Dense (P, c, G, h) of every problem; G, h are None without limit rows."""
         B = q.shape[0]

@@ -27,6 +27,11 @@ class Limit:
     def _spec(self, model) -> Optional[dict]:
         raise NotImplementedError
 
+    def _key(self, model):
+        """Hashable value of ``_spec`` (None for a limit without rows)."""
+        from ._problems import _signature
+        return _signature(self._spec(model))
+
     def compute_qp_inequalities(self, configuration, dt: float) -> Constraint:
         from ._problems import get_problem
         spec = self._spec(configuration.model)
@@ -64,6 +69,11 @@ class ConfigurationLimit(Limit):
         self.gain = gain
         self.min_distance_from_limits = min_distance_from_limits
 
+    def _key(self, model):
+        if self.projection_matrix is None:
+            return None
+        return (L.LIMIT_CONFIGURATION, self.gain, self.min_distance_from_limits)
+
     def _spec(self, model):
         if self.projection_matrix is None:
             return None
@@ -98,6 +108,11 @@ class VelocityLimit(Limit):
         self.limit = np.array(limit_list, dtype=np.float64)
         self.limit.setflags(write=False)
         self.projection_matrix = np.eye(model.nv)[self.indices] if len(self.indices) > 0 else None
+
+    def _key(self, model):
+        if self.projection_matrix is None:
+            return None
+        return (L.LIMIT_VELOCITY, self.indices.tobytes(), self.limit.tobytes())
 
     def _spec(self, model):
         if self.projection_matrix is None:

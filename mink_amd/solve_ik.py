@@ -27,8 +27,12 @@ class Problem(NamedTuple):
 
 def _resolve_limits(configuration, limits):
     if limits is None:
-        return [ConfigurationLimit(configuration.model)]
-    return list(limits)
+        dm = configuration.dmodel
+        default = getattr(dm, "default_limits", None)
+        if default is None:
+            default = dm.default_limits = [ConfigurationLimit(configuration.model)]
+        return default
+    return limits
 
 
 def build_ik(configuration, tasks: Sequence[Task], dt: float, damping: float = 1e-12,
@@ -52,11 +56,20 @@ def solve_ik(configuration, tasks: Sequence[Task], dt: float, solver: str, dampi
     """Velocity ``v`` tangent to the current configuration(s): [nv] numpy for a single
     configuration, [B, nv] device tensor for a batch."""
     _check_solver(solver)
+    if not configuration.batched:
+        # One configuration: the limit check rides along with the solve and one copy brings
+        # back velocity, solver status and the check's result.
+        prob, targets = get_problem(configuration, tasks, _resolve_limits(configuration, limits))
+        v, status, first = prob.solve_single(configuration.q_tensor, targets, dt, damping, tol=1e-6)
+        if first >= 0:
+            configuration._report_limit_violation(0, first, 1, safety_break)
+        assert status == 0, "QP solver failed (infeasible limits or non-finite input)"
+        return v
     configuration.check_limits(safety_break=safety_break)
     prob, targets = get_problem(configuration, tasks, _resolve_limits(configuration, limits))
     v, status = prob.solve(configuration.q_tensor, targets, dt, damping)
     assert int((status != 0).sum()) == 0, "QP solver failed (infeasible limits or non-finite input)"
-    return configuration._out(v)
+    return v
 
 
 def solve_ik_iterate(configuration, tasks: Sequence[Task], dt: float, solver: str, damping: float = 1e-12,
@@ -69,6 +82,11 @@ def solve_ik_iterate(configuration, tasks: Sequence[Task], dt: float, solver: st
     FrameTask, posture-like tasks, Configuration / Velocity limits)."""
     _check_solver(solver)
     prob, targets = get_problem(configuration, tasks, _resolve_limits(configuration, limits))
+    if not configuration.batched:
+        res = prob.iterate_single_(configuration.q_tensor, targets, dt, damping, max_iters, pos_threshold,
+                                   ori_threshold)
+        assert res["status"] == 0, "QP solver failed (infeasible limits or non-finite input)"
+        return res
     res = prob.iterate_(configuration.q_tensor, targets, dt, damping, max_iters, pos_threshold, ori_threshold,
                         want_v=True)
     assert int((res["status"] != 0).sum()) == 0, "QP solver failed (infeasible limits or non-finite input)"

@@ -46,6 +46,12 @@ class Task:
     def _spec(self, model) -> dict:
         raise NotImplementedError
 
+    def _key(self, model):
+        """Hashable value of ``_spec``: problems are cached by it. Subclasses on the
+        per-step path override it with something cheaper than building the descriptor."""
+        from ._problems import _signature
+        return _signature(self._spec(model))
+
     def _target_width(self) -> int:
         return 0
 
@@ -75,14 +81,24 @@ class Task:
         return Objective(configuration._out(P), configuration._out(c))
 
 
-def _pose_target(pose: SE3, configuration, cls_name: str) -> torch.Tensor:
+def _pose_target(task, pose: SE3, configuration) -> torch.Tensor:
+    """[B, 7] device tensor of a pose target; the upload is kept until the task is given
+    another target object (set_target stores a copy, so a new target is a new object)."""
     if pose is None:
-        raise TargetNotSet(cls_name)
+        raise TargetNotSet(task.__class__.__name__)
+    B = configuration.batch_size
+    cached = task.__dict__.get("_target_upload")
+    if cached is not None and cached[0] is pose and cached[1] == configuration.device and cached[2] == B:
+        return cached[3]
     t = pose.wxyz_xyz.to(device=configuration.device, dtype=torch.float64)
     if t.ndim == 1:
-        t = t[None, :].expand(configuration.batch_size, -1)
-    if tuple(t.shape) != (configuration.batch_size, 7):
-        raise InvalidTarget(f"Expected {configuration.batch_size} target poses but got {tuple(t.shape)}")
+        t = t[None, :].expand(B, -1)
+    if tuple(t.shape) != (B, 7):
+        raise InvalidTarget(f"Expected {B} target poses but got {tuple(t.shape)}")
+    t = t.contiguous()
+    if t.data_ptr() == pose.wxyz_xyz.data_ptr():
+        return t   # the caller's own device tensor: it may change under us, so no caching
+    task.__dict__["_target_upload"] = (pose, configuration.device, B, t)
     return t
 
 
@@ -114,6 +130,20 @@ class _FrameCosts(Task):
 
     def _target_width(self) -> int:
         return 7
+
+
+_FRAME_IDS: dict = {}
+
+
+def _frame_ids_cached(model, name, ftype):
+    key = (id(model), name, ftype)
+    hit = _FRAME_IDS.get(key)
+    if hit is None or hit[0] is not model:
+        if len(_FRAME_IDS) > 4096:
+            _FRAME_IDS.clear()
+        hit = (model,) + _frame_ids(model, name, ftype)
+        _FRAME_IDS[key] = hit
+    return hit[1], hit[2]
 
 
 def _frame_ids(model, name, ftype):
@@ -150,8 +180,12 @@ class FrameTask(_FrameCosts):
         return dict(type=L.TASK_FRAME, frame_type=ft, frame_id=fid, cost=self.cost.copy(), gain=self.gain,
                     lm_damping=self.lm_damping)
 
+    def _key(self, model):
+        ft, fid = _frame_ids_cached(model, self.frame_name, self.frame_type)
+        return (L.TASK_FRAME, ft, fid, self.cost.tobytes(), self.gain, self.lm_damping)
+
     def _target_tensor(self, configuration):
-        return _pose_target(self.transform_target_to_world, configuration, self.__class__.__name__)
+        return _pose_target(self, self.transform_target_to_world, configuration)
 
 
 class RelativeFrameTask(_FrameCosts):
@@ -180,8 +214,13 @@ class RelativeFrameTask(_FrameCosts):
         return dict(type=L.TASK_RELATIVE_FRAME, frame_type=ft, frame_id=fid, root_type=rt, root_id=rid,
                     cost=self.cost.copy(), gain=self.gain, lm_damping=self.lm_damping)
 
+    def _key(self, model):
+        ft, fid = _frame_ids_cached(model, self.frame_name, self.frame_type)
+        rt, rid = _frame_ids_cached(model, self.root_name, self.root_type)
+        return (L.TASK_RELATIVE_FRAME, ft, fid, rt, rid, self.cost.tobytes(), self.gain, self.lm_damping)
+
     def _target_tensor(self, configuration):
-        return _pose_target(self.transform_target_to_root, configuration, self.__class__.__name__)
+        return _pose_target(self, self.transform_target_to_root, configuration)
 
 
 class PostureTask(Task):
@@ -223,6 +262,12 @@ class PostureTask(Task):
 
     def _k(self, model) -> int:
         return model.nv
+
+    def _key(self, model):
+        if self.target_q is None:
+            raise TargetNotSet(self.__class__.__name__)
+        return (L.TASK_POSTURE, self.cost.tobytes(), np.asarray(self.target_q, dtype=np.float64).tobytes(),
+                self.gain, self.lm_damping)
 
     def _spec(self, model) -> dict:
         if self.target_q is None:

@@ -138,6 +138,19 @@ def test_caller_loop(model, golden_dir):
         if np.linalg.norm(e[:3]) <= 1e-4 and np.linalg.norm(e[3:]) <= 1e-4:
             break
     assert n == int(g["iters"][k])
+    # the same loop as one launch on the single configuration: plain ints / numpy back
+    cfg1 = mink.Configuration(model, g["q0"][k])
+    res1 = mink.solve_ik_iterate(cfg1, [frame, posture], dt, "quadprog", 1e-3, max_iters=20)
+    assert res1["iters"] == n and res1["status"] == 0
+    np.testing.assert_allclose(cfg1.q, g["q"][k, n - 1], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(res1["v"], g["v"][k, n - 1], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(res1["err"], e, rtol=0, atol=1e-12)
+    # a new target object replaces the cached upload of the previous one
+    frame.set_target(mink.SE3(g["target"][k + 1]))
+    cfg1.update(g["q0"][k + 1])
+    np.testing.assert_allclose(mink.solve_ik(cfg1, [frame, posture], dt, "quadprog", 1e-3), g["v"][k + 1, 0],
+                               rtol=0, atol=1e-8)
+    frame.set_target(mink.SE3(g["target"][k]))
     cfg = mink.Configuration(model, g["q0"])
     frame.set_target(mink.SE3(torch.tensor(g["target"])))
     res = mink.solve_ik_iterate(cfg, [frame, posture], dt, "quadprog", 1e-3, max_iters=20)
