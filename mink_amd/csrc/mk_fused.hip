@@ -307,6 +307,11 @@ MK_DEV void chain_jac(const MkFusedDesc* __restrict__ D, const double (&qc)[NC],
     MK_SCHED_FENCE();
     MK_PIN4(Q.w, Q.x, Q.y, Q.z);
     MK_PIN3(t.x, t.y, t.z);
+    // the column is pinned too: it is only consumed on the not-yet-converged path, and the
+    // optimiser would otherwise sink its arithmetic (and with it the pose and the constants
+    // of every slot) into that branch
+    MK_PIN3(cj.J[0][k], cj.J[1][k], cj.J[2][k]);
+    MK_PIN3(cj.J[3][k], cj.J[4][k], cj.J[5][k]);
     R = q2m(Q);
     s = nx;
   }
@@ -381,7 +386,10 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
     }
   }
 
-  double H[NC * (NC + 1) / 2], c[NC], lo[NC], hi[NC];
+  double c[NC], lo[NC], hi[NC];
+#if defined(MK_ABLATE) && MK_ABLATE == 2
+  double hacc = 0.0;
+#endif
   // one row of H per slot, together with the slot's posture terms and box bounds; padding
   // slots carry W = 1, A = B = 0 and infinite bounds: a decoupled entry with solution 0
   MkDofC dc = D->sdof[0];
@@ -393,12 +401,18 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
       double s = 0.0;
 #pragma unroll
       for (int r = 0; r < 6; ++r) s += Jw[r][i] * Jw[r][j];
-      H[tri(i, j)] = s;
+      if (j == i) s += diag + dc.W;
+      // straight to the lane's LDS column: the solver re-reads H from there, and the
+      // registers are needed for the factor
+#if defined(MK_ABLATE) && MK_ABLATE == 2
+      hacc += s;
+#else
+      hstore[tri(i, j) * hstride] = s;
+#endif
     }
     double s = 0.0;
 #pragma unroll
     for (int r = 0; r < 6; ++r) s += ew[r] * Jw[r][i];
-    H[tri(i, i)] += diag + dc.W;
     c[i] = dc.B * qc[i] - dc.A - s;
     const double vb = dt * dc.vmax;
     hi[i] = fmin(dc.gain * (dc.upper - qc[i]), vb);
@@ -412,18 +426,11 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
   // tuning build only: skip the QP, keep the assembled H / c / bounds alive
   int status = 0;
   {
-    double acc = 0.0;
 #pragma unroll
-    for (int i = 0; i < NC * (NC + 1) / 2; ++i) acc += H[i];
-#pragma unroll
-    for (int i = 0; i < NC; ++i) x[i] = fmin(fmax(-c[i] * 1e-3 + 1e-30 * acc, lo[i]), hi[i]);
+    for (int i = 0; i < NC; ++i) x[i] = fmin(fmax(-c[i] * 1e-3 + 1e-30 * hacc, lo[i]), hi[i]);
   }
 #else
-  // park the Hessian in the lane's LDS column: the solver re-reads it, the registers are
-  // needed for the factor
-#pragma unroll
-  for (int i = 0; i < NC * (NC + 1) / 2; ++i) hstore[i * hstride] = H[i];
-  // keep the compiler from forwarding the stores back into registers
+  // keep the compiler from forwarding the Hessian stores back into registers
   asm volatile("" ::: "memory");
   int status = box_qp<NC>(HView{hstore, hstride}, c, lo, hi, x, act, upper, warm);
 #endif
