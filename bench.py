@@ -22,6 +22,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from mink_amd import _lib as L  # noqa: E402
 from mink_amd import sharding as S  # noqa: E402
 from mink_amd import workloads as W  # noqa: E402
 from mink_amd.engine import DeviceModel, DeviceProblem  # noqa: E402
@@ -104,6 +105,27 @@ def cpu_baseline(model, q0_np, targets_np, gpu_q_final):
     except Exception as e:  # noqa: BLE001
         out["python_numpy_note"] = f"not measured: {e}"
     return out
+
+
+def kkt_residual(prob, q, targets, x):
+    """Worst KKT residual of the solutions x (= dq) over a batch whose inequality rows are all
+    +-e_i (Configuration / Velocity limits): primal infeasibility, and stationarity with the
+    sign conditions of the multipliers (g = P x + c must vanish on interior dofs, be <= 0 at
+    an upper and >= 0 at a lower bound).  Evaluated on the dense (P, c, G, h) the library
+    itself exports, in torch; it is a report, not part of any timed region."""
+    P, c, G, h = prob.build_qp(q, targets, W.DT, W.DAMPING)
+    inf = torch.full_like(h, float("inf"))[:, :, None]
+    hi = torch.where(G > 0.5, h[:, :, None], inf).min(dim=1).values
+    lo = torch.where(G < -0.5, -h[:, :, None], -inf).max(dim=1).values
+    g = torch.einsum("bij,bj->bi", P, x) + c
+    tol = 1e-12
+    at_hi = x >= hi - tol * hi.abs().clamp(min=1.0)
+    at_lo = x <= lo + tol * lo.abs().clamp(min=1.0)
+    stat = torch.where(at_hi, g.clamp(min=0.0), torch.where(at_lo, (-g).clamp(min=0.0), g.abs()))
+    infeas = torch.maximum(x - hi, lo - x).clamp(min=0.0)
+    return {"stationarity_max": float(stat.max().item()), "infeasibility_max": float(infeas.max().item()),
+            "gradient_scale": float(c.abs().max().item()),
+            "active_bounds_mean": float((at_hi | at_lo).double().sum(dim=1).mean().item())}
 
 
 def main():
@@ -231,7 +253,8 @@ def main():
             st = torch.empty(4096, dtype=torch.int32, device=device)
             q2, t2 = q0[:4096].contiguous(), targets[:4096].contiguous()
             w2, e2 = time_launches(lambda i: p2.solve(q2, t2, W.DT, W.DAMPING, v=v, status=st), 200, 20, barrier)
-            extra["config2_B4096_single_step"] = {"solves_per_s": 4096 * 200 / w2, "us_per_launch": 1e6 * e2 / 200}
+            extra["config2_B4096_single_step"] = {"solves_per_s": 4096 * 200 / w2, "us_per_launch": 1e6 * e2 / 200,
+                                                  "kkt": kkt_residual(p2, q2, t2, v * W.DT)}
             # benchmark config 3: 65536 problems x 50 iterated steps, then the early-exit run
             q3 = [q0[:65536].clone() for _ in range(6)]
             t3 = targets[:65536].contiguous()
@@ -245,7 +268,24 @@ def main():
             conv = (r["err"][:, :3].norm(dim=1) <= 1e-4) & (r["err"][:, 3:].norm(dim=1) <= 1e-4)
             extra["config3_early_exit"] = {"fraction_converged": float(conv.double().mean().item()),
                                            "mean_solves": float(it.mean().item()),
-                                           "max_solves": int(it.max().item())}
+                                           "max_solves": int(it.max().item()),
+                                           "final_err_max": {"pos": float(r["err"][:, :3].norm(dim=1).max().item()),
+                                                             "ori": float(r["err"][:, 3:].norm(dim=1).max().item())},
+                                           "note": "far targets at 0.5 m/s, dt = 1/200: most need more than 50 steps"}
+            # the arm + base only model (mobile_kinova.xml, nq = nv = 10), same tasks and limits
+            mk_model = load_builtin("mobile_kinova")
+            mk_dm = DeviceModel(mk_model, device)
+            mk_prob = DeviceProblem(mk_dm, W.task_specs(mk_model, False), W.limit_specs(mk_model, True))
+            rng_k = np.random.default_rng(SEED + 7)
+            Bk = 65536
+            qk0 = torch.tensor(W.sample_q(mk_model, rng_k, Bk), device=device)
+            tk = mk_dm.frame_pose(torch.tensor(W.sample_q(mk_model, rng_k, Bk), device=device),
+                                  L.FRAME_TYPES["site"], mk_model.site_id("pinch_site"))
+            qk = [qk0.clone() for _ in range(6)]
+            wk, ek = time_launches(lambda i: mk_prob.iterate_(qk[i], tk, W.DT, W.DAMPING, ITERS), 5, 1, barrier)
+            extra["mobile_kinova_B65536_x50"] = {"solves_per_s": Bk * ITERS * 5 / wk, "ms_per_launch": 1e3 * ek / 5,
+                                                 "fused": bool(mk_prob.fused), "nv": mk_model.nv}
+            del qk, tk, qk0
             # benchmark config 4: Frame + RelativeFrame + Posture, Cfg + Vel + CollisionAvoidance over the
             # primitive pairs {pads} x {cube, floor}; served by the wave-per-problem kernels
             t4, l4 = W.config4_specs(model)
