@@ -135,14 +135,10 @@ MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const do
   const int kGuessRounds = warm ? 3 : 6;
   MK_STAT(0);
   double L[N * (N + 1) / 2], Ld[N];
-  double u[N];
   uint32_t act = 0u, upper = upper_io;
   bool bad = false;
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    u[i] = 0.0;
-    bad |= !(lo[i] <= hi[i]);
-  }
+  for (int i = 0; i < N; ++i) bad |= !(lo[i] <= hi[i]);
   if (warm) {
     act = act_io;
 #pragma unroll
@@ -175,7 +171,6 @@ MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const do
         const double g = c[i] + hx[i];
         const bool a = (act >> i) & 1u;
         const double ui = ((upper >> i) & 1u) ? -g : g;
-        u[i] = (a && ui > 0.0) ? ui : 0.0;
         if (a && ui < 0.0) drop |= (1u << i);
         if (!a && x[i] - hi[i] > kTol) { add |= (1u << i); add_up |= (1u << i); }
         if (!a && lo[i] - x[i] > kTol) add |= (1u << i);
@@ -195,6 +190,10 @@ MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const do
   bool done = bad;
   int p = -1;
   double sgn = 0.0, bound = 0.0, up_new = 0.0;
+  // multipliers of the active bounds: phase 1 only needs their signs, so they are formed
+  // here, once, and only if some lane of the wave enters phase 2 at all
+  double u[N];
+  bool have_u = false;
   for (int it = 0; it < 6 * N + 8; ++it) {
     if (!done && p < 0) {
       double worst = kTol;
@@ -209,6 +208,18 @@ MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const do
       if (p < 0) done = true;
     }
     if (mk_wave_none(!done)) break;
+    if (!have_u) {   // wave-uniform
+      have_u = true;
+      asm volatile("" ::: "memory");
+      double hx[N];
+      symv<N>(H, x, hx);
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const double g = c[i] + hx[i];
+        const double ui = ((upper >> i) & 1u) ? -g : g;
+        u[i] = (((act >> i) & 1u) && ui > 0.0) ? ui : 0.0;
+      }
+    }
     if (!done) {
       MK_STAT(2);
       asm volatile("" ::: "memory");
