@@ -5,7 +5,8 @@ The kinematics, task and limit assembly and the QP solve run in hand-written HIP
 kernels (mink_amd/csrc) reached through the C ABI of include/mink_amd.h; importing the
 GPU-facing names requires the built extension and PyTorch-ROCm.
 """
-from .constants import FRAME_TO_ENUM, SUPPORTED_FRAMES
+from .constants import (FRAME_TO_ENUM, FRAME_TO_JAC_FUNC, FRAME_TO_POS_ATTR, FRAME_TO_XMAT_ATTR,
+                        SUPPORTED_FRAMES)
 from .exceptions import (InvalidDamping, InvalidFrame, InvalidGain, InvalidKeyframe, InvalidMocapBody, InvalidTarget,
                          LimitDefinitionError, MinkError, NotWithinConfigurationLimits, TargetNotSet,
                          TaskDefinitionError, UnsupportedFrame)
@@ -44,4 +45,5 @@ def __getattr__(name):
 __all__ = tuple(_GPU_NAMES) + (
     "MinkError", "UnsupportedFrame", "InvalidFrame", "InvalidKeyframe", "NotWithinConfigurationLimits",
     "TargetNotSet", "InvalidMocapBody", "InvalidTarget", "InvalidGain", "InvalidDamping", "TaskDefinitionError",
-    "LimitDefinitionError", "SUPPORTED_FRAMES", "FRAME_TO_ENUM", "Model", "load_mjcf", "load_builtin")
+    "LimitDefinitionError", "SUPPORTED_FRAMES", "FRAME_TO_ENUM", "FRAME_TO_JAC_FUNC", "FRAME_TO_POS_ATTR",
+    "FRAME_TO_XMAT_ATTR", "Model", "load_mjcf", "load_builtin")

@@ -24,6 +24,14 @@ def _t(x, like=None) -> torch.Tensor:
     return torch.as_tensor(np.asarray(x, dtype=np.float64), device=dev)
 
 
+def get_epsilon(dtype) -> float:
+    """Small-angle switch of the reference per floating type (mink/lie/utils.py:4-8)."""
+    import numpy as np
+    if isinstance(dtype, torch.dtype):
+        return {torch.float32: 1e-5, torch.float64: 1e-10}[dtype]
+    return {np.dtype("float32"): 1e-5, np.dtype("float64"): 1e-10}[np.dtype(dtype)]
+
+
 def skew(w: torch.Tensor) -> torch.Tensor:
     w = _t(w)
     if w.shape[-1] != 3:

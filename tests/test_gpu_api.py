@@ -241,3 +241,28 @@ def test_mocap_target_ingestion(model):
     mink.move_mocap_to_frame(model, bcfg, "pinch_site_target", "pinch_site", "site")
     Tb = mink.SE3.from_mocap_name(model, bcfg.data, "pinch_site_target")
     same_pose(Tb.wxyz_xyz.cpu().numpy(), bcfg.get_transform_frame_to_world("pinch_site", "site").wxyz_xyz.cpu().numpy(), 1e-15)
+
+
+def test_world_aligned_jacobian_functions(model):
+    """FRAME_TO_JAC_FUNC (mink/constants.py:10-14): world-aligned (jacp, jacr) of a body, geom
+    and site frame against the oracle's mj_jac*, single and batched."""
+    from mink_amd import workloads as W
+    from oracle import ik_oracle as o
+    from oracle import mjlite
+    rng = np.random.default_rng(5)
+    q = W.sample_q(model, rng, 3)
+    frames = {"body": model.body_id("bracelet_link"), "geom": model.geom_id("right_pad1"),
+              "site": model.site_id("pinch_site")}
+    ref = {"body": mjlite.mj_jacBody, "geom": mjlite.mj_jacGeom, "site": mjlite.mj_jacSite}
+    cfg_b = mink.Configuration(model, q)
+    for ftype, fid in frames.items():
+        assert mink.FRAME_TO_JAC_FUNC[ftype].__name__ == ref[ftype].__name__
+        jp_b, jr_b = mink.FRAME_TO_JAC_FUNC[ftype](cfg_b, fid)
+        for b in range(3):
+            oc = o.Configuration(model, q[b])
+            jp, jr = ref[ftype](oc.model, oc.data, fid)
+            np.testing.assert_allclose(jp_b[b].cpu().numpy(), jp, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(jr_b[b].cpu().numpy(), jr, rtol=0, atol=1e-12)
+        jp1, jr1 = mink.FRAME_TO_JAC_FUNC[ftype](mink.Configuration(model, q[0]), fid)
+        assert jp1.shape == (3, model.nv) and isinstance(jp1, np.ndarray)
+        np.testing.assert_allclose(jp1, jp_b[0].cpu().numpy(), rtol=0, atol=0)
