@@ -266,3 +266,50 @@ def test_world_aligned_jacobian_functions(model):
         jp1, jr1 = mink.FRAME_TO_JAC_FUNC[ftype](mink.Configuration(model, q[0]), fid)
         assert jp1.shape == (3, model.nv) and isinstance(jp1, np.ndarray)
         np.testing.assert_allclose(jp1, jp_b[0].cpu().numpy(), rtol=0, atol=0)
+
+
+def test_iterated_loop_on_the_general_path(model):
+    """solve_ik_iterate with a RelativeFrameTask and a CollisionAvoidanceLimit (problems the
+    fused kernels do not serve): the callers' loop, per problem, against the oracle."""
+    from mink_amd import workloads as W
+    from oracle import ik_oracle as o
+    rng = np.random.default_rng(21)
+    B, dt, max_iters = 6, W.DT, 12
+    q0 = W.sample_q(model, rng, B)
+    bcfg = mink.Configuration(model, q0)
+    T0 = bcfg.get_transform_frame_to_world("pinch_site", "site").wxyz_xyz.cpu().numpy()
+    tg = W.offset_targets(T0, rng)
+    tg[:2] = T0[:2]                                                # two problems start on their target
+    Trel = bcfg.get_transform("pinch_site", "site", "base_link", "body").wxyz_xyz.cpu().numpy()
+    frame = mink.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0)
+    rel = mink.RelativeFrameTask("pinch_site", "site", "base_link", "body", 0.3, 0.3)
+    posture = mink.PostureTask(model, cost=W.posture_cost(model))
+    posture.set_target(W.home_q(model))
+    frame.set_target(mink.SE3(torch.tensor(tg)))
+    rel.set_target(mink.SE3(torch.tensor(Trel)))
+    pads = ["right_pad1", "right_pad2", "left_pad1", "left_pad2"]
+    limits = [mink.ConfigurationLimit(model), mink.VelocityLimit(model, W.VELOCITY_LIMITS),
+              mink.CollisionAvoidanceLimit(model, [(pads, ["cube_geom", "floor"])])]
+    res = mink.solve_ik_iterate(bcfg, [frame, rel, posture], dt, "quadprog", W.DAMPING, max_iters=max_iters,
+                                pos_threshold=1e-4, ori_threshold=1e-4, limits=limits)
+    iters = res["iters"].cpu().numpy()
+    olim = [o.ConfigurationLimit(model), o.VelocityLimit(model, W.VELOCITY_LIMITS),
+            o.CollisionAvoidanceLimit(model, [(pads, ["cube_geom", "floor"])])]
+    for b in range(B):
+        cfg = o.Configuration(model, q0[b])
+        otasks = [o.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0, target=tg[b]),
+                  o.RelativeFrameTask("pinch_site", "site", "base_link", "body", 0.3, 0.3, target=Trel[b]),
+                  o.PostureTask(cost=W.posture_cost(model), target_q=W.home_q(model))]
+        n = 0
+        for it in range(max_iters):
+            v = o.solve_ik(cfg, otasks, dt, damping=W.DAMPING, limits=olim)
+            cfg.integrate_inplace(v, dt)
+            n = it + 1
+            e = otasks[0].error(cfg)
+            if np.linalg.norm(e[:3]) <= 1e-4 and np.linalg.norm(e[3:]) <= 1e-4:
+                break
+        assert iters[b] == n, (b, iters[b], n)
+        np.testing.assert_allclose(bcfg.q[b].cpu().numpy(), cfg.q, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(res["err"][b].cpu().numpy(), e, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(res["v"][b].cpu().numpy(), v, rtol=0, atol=1e-8)
+    assert iters.min() < max_iters and iters.max() == max_iters
