@@ -704,9 +704,11 @@ struct EmitDof {
   }
 };
 
-// Whole-tree forward kinematics: lane l walks the path root -> body l (+64, ...), so all
-// bodies advance together; the last body of a walk is the lane's own, whose dofs it emits.
-MK_GPU void tree_fk(const MkDevModel& m, WLds& s, int lane) {
+// Whole-tree forward kinematics by path walking: lane l walks the path root -> body l
+// (+64, ...), so all bodies advance together; the last body of a walk is the lane's own,
+// whose dofs it emits.  Any tree size; every step of a walk waits on the table loads of
+// its body, so this is the slow path, used when the tree has more than 64 bodies.
+MK_GPU void tree_fk_walk(const MkDevModel& m, WLds& s, int lane) {
   EmitDof em{s.daxis, s.danch, s.dkind, false};
   for (int b0 = 0; b0 < m.nbody; b0 += 64) {
     const int body = b0 + lane;
@@ -729,6 +731,64 @@ MK_GPU void tree_fk(const MkDevModel& m, WLds& s, int lane) {
     }
   }
   __syncthreads();
+}
+
+// Dof axes / anchors in the frame of the body's parent, tagged with that parent.
+struct EmitDofLocal {
+  double *daxis, *danch;
+  int32_t* dkind;
+  int parent;
+  MK_GPU void operator()(int dof, int kind, V3 ax, V3 an) {
+    daxis[3 * dof] = ax.x; daxis[3 * dof + 1] = ax.y; daxis[3 * dof + 2] = ax.z;
+    danch[3 * dof] = an.x; danch[3 * dof + 1] = an.y; danch[3 * dof + 2] = an.z;
+    dkind[dof] = kind + 2 * parent;
+  }
+};
+
+// Whole-tree forward kinematics for trees of at most 64 bodies, lane = body, in three
+// passes whose table loads are all issued up front:
+//   A  every body's transform relative to its parent (offset, then its joints at q) and
+//      its dofs' axes / anchors in the parent's frame -- no dependence on other bodies;
+//   B  level by level from the root, world pose = parent's world pose (LDS) o local;
+//   C  (by the caller, lane = dof) the dof's axis / anchor moved to the world frame with
+//      the parent's world pose.
+// A body on a free joint carries its absolute pose and is composed with the world body.
+MK_GPU void tree_fk_levels(const MkDevModel& m, WLds& s, int lane) {
+  const int body = lane;
+  const bool has = body < m.nbody;
+  int depth = 0, parent = 0;
+  BodyState st = body_state_identity();
+  if (has) {
+    depth = m.path_len[body];
+    const int ja = m.body_jntadr[body], jn = m.body_jntnum[body];
+    const bool absolute = jn == 1 && m.jnt_type[ja] == MK_JNT_FREE;
+    parent = absolute ? 0 : m.body_parentid[body];
+    EmitDofLocal em{s.daxis, s.danch, s.dkind, parent};
+    advance_body<true>(m, s.q, body, st, em);
+    if (depth == 0) {
+      s.bpos[3 * body] = st.p.x; s.bpos[3 * body + 1] = st.p.y; s.bpos[3 * body + 2] = st.p.z;
+      s.bquat[4 * body] = st.Q.w; s.bquat[4 * body + 1] = st.Q.x; s.bquat[4 * body + 2] = st.Q.y;
+      s.bquat[4 * body + 3] = st.Q.z;
+    }
+  }
+  int maxdepth = depth;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) maxdepth = max(maxdepth, __shfl_xor(maxdepth, o));
+  __syncthreads();
+  for (int d = 1; d <= maxdepth; ++d) {
+    if (has && depth == d) {
+      V3 pp;
+      Q4 pq;
+      pp = v3(s.bpos[3 * parent], s.bpos[3 * parent + 1], s.bpos[3 * parent + 2]);
+      pq = Q4{s.bquat[4 * parent], s.bquat[4 * parent + 1], s.bquat[4 * parent + 2], s.bquat[4 * parent + 3]};
+      const V3 pw = pp + qrot(pq, st.p);
+      const Q4 qw = qnormalize(qmul(pq, st.Q));
+      s.bpos[3 * body] = pw.x; s.bpos[3 * body + 1] = pw.y; s.bpos[3 * body + 2] = pw.z;
+      s.bquat[4 * body] = qw.w; s.bquat[4 * body + 1] = qw.x; s.bquat[4 * body + 2] = qw.y;
+      s.bquat[4 * body + 3] = qw.z;
+    }
+    __syncthreads();
+  }
 }
 
 // The lane's own dof: how it moves a point attached to a body whose path contains it.
@@ -796,12 +856,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int i = lane; i < 3 * n; i += 64) { s.daxis[i] = 0.0; s.danch[i] = 0.0; }
     __syncthreads();
     if (own) s.P[lane * np + lane] = damping;
-    tree_fk(m, s, lane);
     DofCol dc;
     dc.lane = lane;
-    dc.kind = own ? s.dkind[lane] : MK_COL_LIN;
-    dc.axis = own ? v3(s.daxis[3 * lane], s.daxis[3 * lane + 1], s.daxis[3 * lane + 2]) : v3(0, 0, 0);
-    dc.anchor = own ? v3(s.danch[3 * lane], s.danch[3 * lane + 1], s.danch[3 * lane + 2]) : v3(0, 0, 0);
+    dc.kind = MK_COL_LIN;
+    dc.axis = v3(0, 0, 0);
+    dc.anchor = v3(0, 0, 0);
+    if (m.nbody <= 64) {
+      tree_fk_levels(m, s, lane);
+      if (own) {
+        // pass C: the lane's dof, from the frame of its body's parent to the world
+        const int tag = s.dkind[lane], par = tag >> 1;
+        V3 pp;
+        Q4 pq;
+        body_pose(s, par, pp, pq);
+        dc.kind = tag & 1;
+        dc.axis = qrot(pq, v3(s.daxis[3 * lane], s.daxis[3 * lane + 1], s.daxis[3 * lane + 2]));
+        dc.anchor = pp + qrot(pq, v3(s.danch[3 * lane], s.danch[3 * lane + 1], s.danch[3 * lane + 2]));
+      }
+    } else {
+      tree_fk_walk(m, s, lane);
+      if (own) {
+        dc.kind = s.dkind[lane];
+        dc.axis = v3(s.daxis[3 * lane], s.daxis[3 * lane + 1], s.daxis[3 * lane + 2]);
+        dc.anchor = v3(s.danch[3 * lane], s.danch[3 * lane + 1], s.danch[3 * lane + 2]);
+      }
+    }
     const double* qb = s.q;
     const double* tg = s.tg;
 #if defined(MK_DENSE_ABLATE) && MK_DENSE_ABLATE == 1
