@@ -167,8 +167,10 @@ MK_GPU void box_edge(V3 c, const M3& r, V3 h, int e, V3& a0, V3& a1) {
 // overlap, witnesses around the midpoint of the two support points), otherwise exact
 // closest points over the 8 + 8 vertex-box and 12 x 12 edge-edge candidates, spread over
 // the lanes.  Candidates are numbered in a fixed order and the first strict minimum wins,
-// so the result does not depend on how they are distributed.
-MK_GPU Contact box_box_wave(int lane, V3 c1, const M3& r1, V3 h1, V3 c2, const M3& r2, V3 h2) {
+// so the result does not depend on how they are distributed.  A separated pair whose gap
+// along some candidate axis is already >= distmax returns that gap (the caller only needs
+// to know that the pair is out of range).
+MK_GPU Contact box_box_wave(int lane, V3 c1, const M3& r1, V3 h1, V3 c2, const M3& r2, V3 h2, double distmax) {
   const V3 d = c2 - c1;
   double overlap = INFINITY;
   V3 axis = v3(1, 0, 0);
@@ -206,6 +208,19 @@ MK_GPU Contact box_box_wave(int lane, V3 c1, const M3& r1, V3 h1, V3 c2, const M
     ct.p1 = pos - (0.5 * ct.dist) * n;
     ct.p2 = pos + (0.5 * ct.dist) * n;
     return ct;
+  }
+  {
+    // the gap along a separating axis is a lower bound of the distance: a pair that is
+    // farther apart than distmax along any of them is done without the closest-point search
+    double gap = (lane < 15 && overlap < INFINITY) ? -overlap : -INFINITY;
+    int gid = lane;
+    wave_argmax(gap, gid);
+    if (gap >= distmax) {
+      ct.dist = gap;
+      ct.p1 = c1;
+      ct.p2 = c2;
+      return ct;
+    }
   }
   double best = INFINITY;
   int bi = 1 << 30;
@@ -320,7 +335,7 @@ MK_GPU bool geom_distance(int lane, int t1, V3 c1, const M3& r1, V3 s1, int t2, 
     const V3 d = c2 - c1;
     const double far = sqrt(dot(d, d)) - sqrt(dot(s1, s1)) - sqrt(dot(s2, s2));
     if (far >= distmax) return false;
-    ct = box_box_wave(lane, c1, r1, s1, c2, r2, s2);
+    ct = box_box_wave(lane, c1, r1, s1, c2, r2, s2, distmax);
   }
   return ct.dist < distmax;
 }
@@ -449,16 +464,16 @@ MK_GPU double readlane_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-// Register-resident version of chol_rows + invert_from_chol for n <= NP: lane i keeps row
-// i of P / L in registers, then column i of L^-1, then row i of H^-1, and reads other
+// Register-resident version of chol_rows + invert_from_chol for an n x n matrix M (rows in
+// LDS, stride np), n <= NP, inverted in place: lane i keeps row
+// i of M / L in registers, then column i of L^-1, then row i of H^-1, and reads other
 // lanes' entries with readlane.  Fully unrolled: about 3 x n^2/2 fused multiply-adds and
 // as many lane reads, no barriers and no LDS traffic until H^-1 is written out.
 template <int NP>
-__device__ __attribute__((noinline)) bool invert_regs(WLds& s, int n, int lane) {
-  const int np = s.npad;
+__device__ __attribute__((noinline)) bool invert_regs(double* M, int np, int n, int lane) {
   double A[NP];
 #pragma unroll
-  for (int j = 0; j < NP; ++j) A[j] = (lane < n && j < n) ? s.P[lane * np + j] : 0.0;
+  for (int j = 0; j < NP; ++j) A[j] = (lane < n && j < n) ? M[lane * np + j] : 0.0;
   // (lane j keeps 1 / L_jj in place of L_jj: only the reciprocal is used afterwards)
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
@@ -498,7 +513,7 @@ __device__ __attribute__((noinline)) bool invert_regs(WLds& s, int n, int lane) 
       double acc = 0.0;
 #pragma unroll
       for (int k = j; k < NP; ++k) acc += Wc[k] * readlane_f64(Wc[k], j);
-      if (lane < n) s.P[lane * np + j] = acc;
+      if (lane < n) M[lane * np + j] = acc;
     }
     MK_SCHED_FENCE();
   }
@@ -515,9 +530,11 @@ __device__ __attribute__((noinline)) bool invert_regs(WLds& s, int n, int lane) 
 MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, double& x_out) {
   const int np = s.npad, na1 = s.na1;
   if (n <= 16) {
-    if (!invert_regs<16>(s, n, lane)) return 3;
+    if (!invert_regs<16>(s.P, np, n, lane)) return 3;
+  } else if (n <= 24) {
+    if (!invert_regs<24>(s.P, np, n, lane)) return 3;
   } else if (n <= 32) {
-    if (!invert_regs<32>(s, n, lane)) return 3;
+    if (!invert_regs<32>(s.P, np, n, lane)) return 3;
   } else {
     if (!chol_rows(s, n, lane)) return 3;
     invert_from_chol(s, n, lane);
@@ -542,6 +559,76 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
   bool act_hi = false, act_lo = false;
   int na = 0;
   int status = 1;
+  // ---- block start: all bounds violated at the unconstrained minimiser at once ----
+  // With A = those bounds, x = x0 - H^-1 N u, u = (N'H^-1N)^-1 (N'x0 - b) is the minimiser on
+  // the face A; if every u_a >= 0 this is an S-pair and the dual method may start from it
+  // (one small inversion instead of one step per bound).  Bounds whose multiplier comes out
+  // negative are taken out and the face is solved again; after three tries the method
+  // starts from the empty set as usual.  Bounds on distinct dofs are linearly independent.
+  {
+    uint64_t mh = __ballot(lane < n && x - hi > 1e-12);
+    uint64_t ml = __ballot(lane < n && lo - x > 1e-12);
+    for (int attempt = 0; attempt < 3 && (mh | ml) != 0ull; ++attempt) {
+      const uint64_t mm = mh | ml;
+      const int cnt = __popcll(mm);
+      if (cnt > 24) break;
+      const bool mine = (mm >> lane) & 1ull;
+      const int slot = __popcll(mm & ((1ull << lane) - 1ull));
+      if (mine) s.act[slot] = ((mh >> lane) & 1ull) ? lane : n + lane;
+      __syncthreads();
+      // lane a < cnt: its constraint, the Gram matrix row and the violation
+      const int ida = lane < cnt ? s.act[lane] : 0;
+      const int ja = ida < n ? ida : ida - n;
+      const double sa = ida < n ? 1.0 : -1.0;
+      const double xj = __shfl(x, ja), hj = __shfl(hi, ja), lj = __shfl(lo, ja);
+      const double viol = lane < cnt ? (ida < n ? xj - hj : lj - xj) : 0.0;
+      if (lane < cnt) {
+        double* mr = s.Minv + lane * na1;
+        for (int b2 = 0; b2 < cnt; ++b2) {
+          const int idb = s.act[b2];
+          const int jb = idb < n ? idb : idb - n;
+          mr[b2] = (idb < n ? sa : -sa) * Hi[ja * np + jb];
+        }
+      }
+      __syncthreads();
+      const bool ok = cnt <= 16 ? invert_regs<16>(s.Minv, na1, cnt, lane) : invert_regs<24>(s.Minv, na1, cnt, lane);
+      if (!ok) break;
+      double ua = 0.0;
+      {
+        const double* mr = s.Minv + (lane < cnt ? lane : 0) * na1;
+        for (int b2 = 0; b2 < cnt; ++b2) ua += mr[b2] * readlane_f64(viol, b2);
+        if (lane >= cnt) ua = 0.0;
+      }
+      const uint64_t negm = __ballot(lane < cnt && ua < 0.0);
+      if (negm != 0ull) {
+        // take the bounds with a negative multiplier out of the candidate set
+        const double us = __shfl(ua, slot);
+        const uint64_t dropm = __ballot(mine && us < 0.0);
+        mh &= ~dropm;
+        ml &= ~dropm;
+        __syncthreads();
+        continue;
+      }
+      // accepted: x, H^-1 N, multipliers, flags
+      for (int a = 0; a < cnt; ++a) {
+        const int idb = s.act[a];
+        const int jb = idb < n ? idb : idb - n;
+        const double sb = idb < n ? 1.0 : -1.0;
+        const double hcol = lane < n ? sb * Hi[jb * np + lane] : 0.0;   // (H^-1 n_a)_lane
+        if (lane < n) s.HiN[a * np + lane] = hcol;
+        x -= hcol * readlane_f64(ua, a);
+      }
+      if (lane < cnt) s.u[lane] = ua;
+      act_hi = (mh >> lane) & 1ull;
+      act_lo = (ml >> lane) & 1ull;
+      na = cnt;
+      __syncthreads();
+      break;
+    }
+  }
+#if defined(MK_DENSE_COUNT_STEPS)
+  int n_full = 0, n_partial = 0;   // tuning build only: step counts returned in place of the status
+#endif
   const int max_iter = 10 * (mg + 3 * n);
   for (int it = 0; it < max_iter; ++it) {
     // ---- most violated constraint (normalised by the row norm) ----
@@ -656,10 +743,16 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
         if (p < n && lane == p) act_hi = true;
         if (p >= n && p < 2 * n && lane == p - n) act_lo = true;
         ++na;
+#if defined(MK_DENSE_COUNT_STEPS)
+        ++n_full;
+#endif
         __syncthreads();
         break;
       }
       // partial step: the blocking constraint kb leaves the active set
+#if defined(MK_DENSE_COUNT_STEPS)
+      ++n_partial;
+#endif
       __syncthreads();
       const int idk = s.act[kb];
       if (idk < n) { if (lane == idk) act_hi = false; }
@@ -687,6 +780,9 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
     if (failed) break;
   }
   x_out = x;
+#if defined(MK_DENSE_COUNT_STEPS)
+  return n_full + 100 * n_partial;
+#endif
   return status;
 }
 
@@ -833,7 +929,10 @@ MK_GPU Frame eval_frame(const MkDevModel& m, const WLds& s, int body, const doub
 }
 
 // ---------------------------------------------------------------- kernels ----
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_kernel(MkDevModel m, const MkDenseProblem* __restrict__ prob, int n_rows,
+#ifndef MK_DENSE_WPE
+#define MK_DENSE_WPE 2
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MK_DENSE_WPE, MK_DENSE_WPE))) void dense_kernel(MkDevModel m, const MkDenseProblem* __restrict__ prob, int n_rows,
                                                    int n_general, int npath, const double* __restrict__ q,
                                                    const double* __restrict__ targets, int target_stride, double dt,
                                                    double damping, int B, double* __restrict__ P_out,
