@@ -15,6 +15,10 @@
  *     asynchronous on it and never synchronise;
  *   - functions return MK_OK or a negative error code, never throw; the message of
  *     the last failure on the calling thread is available from mk_last_error();
+ *   - a model / problem handle belongs to the device that was current when it was
+ *     created; batch calls made while another device is current fail with
+ *     MK_ERR_INVALID (one process per GPU never meets this); handles are immutable
+ *     after creation and may be used from several threads / streams at once;
  *   - per-problem solver outcome goes to an int32 status array:
  *       0 solved, 1 iteration limit, 2 infeasible constraints, 3 non-finite input.
  *   - quaternions are (w, x, y, z); poses are (qw, qx, qy, qz, x, y, z) like

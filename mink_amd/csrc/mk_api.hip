@@ -121,6 +121,21 @@ struct mk_problem {
 
 namespace {
 
+// A handle's tables live on the device that was current when it was created; a launch from
+// another device would hand the kernels pointers of a foreign address space.
+int check_device(const mk_model* m) {
+  int cur = -1;
+  MK_HIP(hipGetDevice(&cur));
+  if (cur != m->device)
+    return fail(MK_ERR_INVALID, "the handle was created on device %d but the current device is %d", m->device, cur);
+  return MK_OK;
+}
+#define MK_ON_DEVICE(model)                  \
+  do {                                       \
+    const int _rc = check_device(model);     \
+    if (_rc != MK_OK) return _rc;            \
+  } while (0)
+
 template <typename T>
 int upload(std::vector<void*>& allocs, const std::vector<T>& v, const T** out) {
   void* p = nullptr;
@@ -758,6 +773,7 @@ int mk_solve_ik_batch(const mk_problem* p, const double* d_q, const double* d_ta
   if (!p) return fail(MK_ERR_INVALID, "null problem");
   if (B < 0 || !(dt > 0.0) || !(damping >= 0.0)) return fail(MK_ERR_INVALID, "B, dt or damping out of range");
   if (B == 0) return MK_OK;
+  MK_ON_DEVICE(p->model);
   if (!d_q || !d_v || !d_status) return fail(MK_ERR_INVALID, "null argument");
   if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
   if (!p->fused) {
@@ -777,6 +793,7 @@ int mk_solve_ik_iterate_batch(const mk_problem* p, double* d_q, const double* d_
   if (!p) return fail(MK_ERR_INVALID, "null problem");
   if (B < 0 || max_iters < 0 || !(dt > 0.0) || !(damping >= 0.0)) return fail(MK_ERR_INVALID, "B, max_iters, dt or damping out of range");
   if (B == 0) return MK_OK;
+  MK_ON_DEVICE(p->model);
   if (!d_q || !d_status) return fail(MK_ERR_INVALID, "null argument");
   if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
   if (!p->fused) return fail(MK_ERR_UNSUPPORTED, "the iterated solve needs a problem the fused path serves");
@@ -789,6 +806,7 @@ int mk_solve_ik_iterate_batch(const mk_problem* p, double* d_q, const double* d_
 int mk_integrate_batch(const mk_model* m, double* d_q, const double* d_v, double dt, int32_t B, void* stream) {
   if (!m || B < 0) return fail(MK_ERR_INVALID, "null model or negative batch");
   if (B == 0) return MK_OK;
+  MK_ON_DEVICE(m);
   if (!d_q || !d_v) return fail(MK_ERR_INVALID, "null argument");
   MK_HIP(mk_generic_integrate(m->dev, d_q, d_v, dt, B, static_cast<hipStream_t>(stream)));
   return MK_OK;
@@ -803,6 +821,7 @@ int mk_fk_batch(const mk_model* m, const double* d_q, int32_t B, int32_t frame_t
   int rc = frame_body_and_local(m->h, frame_type, frame_id, &body, lpos, lquat);
   if (rc != MK_OK) return rc;
   if (B == 0) return MK_OK;
+  MK_ON_DEVICE(m);
   MK_HIP(mk_generic_frame(m->dev, d_q, B, body, lpos, lquat, d_pose, nullptr, static_cast<hipStream_t>(stream)));
   return MK_OK;
 }
@@ -816,6 +835,7 @@ int mk_frame_jacobian_batch(const mk_model* m, const double* d_q, int32_t B, int
   int rc = frame_body_and_local(m->h, frame_type, frame_id, &body, lpos, lquat);
   if (rc != MK_OK) return rc;
   if (B == 0) return MK_OK;
+  MK_ON_DEVICE(m);
   MK_HIP(mk_generic_frame(m->dev, d_q, B, body, lpos, lquat, nullptr, d_jac, static_cast<hipStream_t>(stream)));
   return MK_OK;
 }
@@ -823,6 +843,7 @@ int mk_frame_jacobian_batch(const mk_model* m, const double* d_q, int32_t B, int
 int mk_check_limits_batch(const mk_model* m, const double* d_q, double tol, int32_t B, int32_t* d_first, void* stream) {
   if (!m || B < 0) return fail(MK_ERR_INVALID, "null model or negative batch");
   if (B == 0) return MK_OK;
+  MK_ON_DEVICE(m);
   if (!d_q || !d_first) return fail(MK_ERR_INVALID, "null argument");
   MK_HIP(mk_generic_check_limits(m->dev, d_q, tol, B, d_first, static_cast<hipStream_t>(stream)));
   return MK_OK;
@@ -833,6 +854,7 @@ int mk_build_qp_batch(const mk_problem* p, const double* d_q, const double* d_ta
   if (!p) return fail(MK_ERR_INVALID, "null problem");
   if (B < 0 || !(dt > 0.0) || !(damping >= 0.0)) return fail(MK_ERR_INVALID, "B, dt or damping out of range");
   if (B == 0) return MK_OK;
+  MK_ON_DEVICE(p->model);
   if (!d_q || !d_P || !d_c) return fail(MK_ERR_INVALID, "null argument");
   if (p->info.n_rows > 0 && (!d_G || !d_h)) return fail(MK_ERR_INVALID, "G and h are required when the problem has limits");
   if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
@@ -848,6 +870,7 @@ int mk_task_eval_batch(const mk_problem* p, int32_t task, const double* d_q, con
   if (!p) return fail(MK_ERR_INVALID, "null problem");
   if (B < 0 || task < 0 || task >= p->h_dense.ntask) return fail(MK_ERR_INVALID, "batch or task index out of range");
   if (B == 0) return MK_OK;
+  MK_ON_DEVICE(p->model);
   if (!d_q || (!d_err && !d_jac)) return fail(MK_ERR_INVALID, "null argument");
   if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
   if (!p->dense) return fail(MK_ERR_UNSUPPORTED, "dense path unavailable: %s", p->dense_why.c_str());
