@@ -312,6 +312,8 @@ def main():
             ptask = mk.PostureTask(model, cost=W.posture_cost(model))
             ptask.set_target(W.home_q(model))
             wcfg = mk.LinearWaypointReachConfig(0.01, 0.08, 0.05, 0.3)
+            mk.move_to(mk.Configuration(model, rq[:4096].clone(), device=device), ftask, [ftask, ptask],
+                       goal_pos[:4096], mk.SO3(goal_rot.wxyz[:4096]), wcfg, max_steps=50)   # warm-up
             torch.cuda.synchronize()
             tr = time.perf_counter()
             ro = mk.move_to(rcfg, ftask, [ftask, ptask], goal_pos, goal_rot, wcfg, max_steps=50)
@@ -322,7 +324,7 @@ def main():
                 "mean_waypoint_steps": float(ro["steps"].double().mean().item()),
                 "ik_solves_per_s": float(ro["solves"].sum().item()) / tr,
                 "note": "kinematic part of the reference's move_to (waypoint generator + <=20-iteration IK loop per "
-                        "step, default ConfigurationLimit), physics excluded"}
+                        "step, default ConfigurationLimit) as one launch (mk_move_to_batch), physics excluded"}
             res["other_workloads"] = extra
         if n_gpus == 1 and not args.no_cpu_baseline:
             torch.cuda.synchronize()

@@ -155,6 +155,29 @@ int mk_solve_ik_iterate_batch(const mk_problem* problem, double* d_q, const doub
                               double pos_tol, double ori_tol, double* d_v, int32_t* d_iters,
                               double* d_err, int32_t* d_status, void* stream);
 
+/* Waypoint generator parameters: envs/robot_utils.py:113-118 (LinearWaypointReachConfig;
+ * its rot_step_size is not used by the reference's step() and is kept for layout only). */
+typedef struct mk_waypoint_config {
+  double pos_threshold, pos_step_size, rot_threshold, rot_step_size;
+} mk_waypoint_config;
+
+/* Kinematic part of the reference's move_to (envs/mj_env.py:193-276): up to max_steps x
+ * { pose of the problem's frame task; LinearWaypointReach.step (envs/robot_utils.py:131-160:
+ * bounded linear position step, half-way slerp, reached test on the position distance and
+ * the x-y-z Euler angles of goal * current^-1); the callers' IK loop of
+ * mk_solve_ik_iterate_batch towards the commanded pose }, a problem stopping after the
+ * step in which its generator reports the goal reached.  The configuration is taken to
+ * track its IK solution (the reference hands it to the MuJoCo simulation instead).
+ * d_q [B, nq] is updated in place; d_goals [B, 7] goal poses (wxyz_xyz) of the frame task;
+ * outputs (d_steps, d_reached, d_solves may be NULL): outer steps taken, 1 if reached,
+ * IK solves executed, and the worst solver status [B].  Needs a problem of the fused path
+ * with a single frame task. */
+int mk_move_to_batch(const mk_problem* problem, double* d_q, const double* d_goals,
+                     const mk_waypoint_config* wp, double dt, double damping, int32_t B,
+                     int32_t max_steps, int32_t max_iters, double pos_tol, double ori_tol,
+                     int32_t* d_steps, int32_t* d_reached, int32_t* d_solves, int32_t* d_status,
+                     void* stream);
+
 /* Configuration.integrate_inplace minus the FK refresh (mink/configuration.py:228-236,
  * i.e. mujoco.mj_integratePos): d_q [B, nq] <- d_q (+) dt * d_v [B, nv]. */
 int mk_integrate_batch(const mk_model* model, double* d_q, const double* d_v, double dt,

@@ -67,6 +67,11 @@ class ProblemInfo(C.Structure):
                 ("n_rows", C.c_int32), ("fused", C.c_int32), ("n_chain", C.c_int32)]
 
 
+class WaypointConfig(C.Structure):
+    _fields_ = [("pos_threshold", C.c_double), ("pos_step_size", C.c_double), ("rot_threshold", C.c_double),
+                ("rot_step_size", C.c_double)]
+
+
 def _i32(a) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(a), dtype=np.int32)
 
@@ -155,6 +160,9 @@ _SIGNATURES = {
     "mk_solve_ik_iterate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int32,
                                             C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),
+    "mk_move_to_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int32,
+                                   C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
     "mk_integrate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_void_p]),
     "mk_fk_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mk_frame_jacobian_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

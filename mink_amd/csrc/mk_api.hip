@@ -23,6 +23,11 @@ hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, do
                                    int target_stride, double dt, double damping, int B, int max_iters,
                                    double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
                                    int32_t* status, hipStream_t stream);
+hipError_t mk_fused_launch_move_to(int nc, const MkFusedDesc* d_desc, int nq, double* q, const double* goals,
+                                   double dt, double damping, int B, int max_steps, int max_iters, double pos_tol,
+                                   double ori_tol, double wp_pos_thr, double wp_pos_step, double wp_rot_thr,
+                                   int32_t* steps, int32_t* reached, int32_t* solves, int32_t* status,
+                                   hipStream_t stream);
 
 namespace {
 
@@ -800,6 +805,25 @@ int mk_solve_ik_iterate_batch(const mk_problem* p, double* d_q, const double* d_
   MK_HIP(mk_fused_launch_iterate(p->nc_kernel, p->d_fused, p->info.nq, d_q, d_targets, p->info.target_stride, dt,
                                  damping, B, max_iters, pos_tol, ori_tol, d_v, d_iters, d_err, d_status,
                                  static_cast<hipStream_t>(stream)));
+  return MK_OK;
+}
+
+int mk_move_to_batch(const mk_problem* p, double* d_q, const double* d_goals, const mk_waypoint_config* wp, double dt,
+                     double damping, int32_t B, int32_t max_steps, int32_t max_iters, double pos_tol, double ori_tol,
+                     int32_t* d_steps, int32_t* d_reached, int32_t* d_solves, int32_t* d_status, void* stream) {
+  if (!p || !wp) return fail(MK_ERR_INVALID, "null problem or waypoint configuration");
+  if (B < 0 || max_steps < 0 || max_iters < 0 || !(dt > 0.0) || !(damping >= 0.0))
+    return fail(MK_ERR_INVALID, "B, max_steps, max_iters, dt or damping out of range");
+  if (!(wp->pos_threshold >= 0.0) || !(wp->pos_step_size > 0.0) || !(wp->rot_threshold >= 0.0))
+    return fail(MK_ERR_INVALID, "waypoint thresholds / step size out of range");
+  if (B == 0) return MK_OK;
+  MK_ON_DEVICE(p->model);
+  if (!d_q || !d_goals || !d_status) return fail(MK_ERR_INVALID, "null argument");
+  if (!p->fused) return fail(MK_ERR_UNSUPPORTED, "waypoint reaching needs a problem the fused path serves");
+  if (p->info.target_stride != 7) return fail(MK_ERR_UNSUPPORTED, "waypoint reaching drives exactly one frame task");
+  MK_HIP(mk_fused_launch_move_to(p->nc_kernel, p->d_fused, p->info.nq, d_q, d_goals, dt, damping, B, max_steps, max_iters,
+                                 pos_tol, ori_tol, wp->pos_threshold, wp->pos_step_size, wp->rot_threshold, d_steps,
+                                 d_reached, d_solves, d_status, static_cast<hipStream_t>(stream)));
   return MK_OK;
 }
 

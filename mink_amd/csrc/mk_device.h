@@ -295,6 +295,27 @@ MK_DEV V3 so3_log(Q4 q) {
   return V3{f * q.x, f * q.y, f * q.z};
 }
 
+// SO3.exp of a rotation vector (mink/lie/so3.py:158-173): unit quaternion, with the
+// reference's series below its small-angle switch.
+MK_DEV Q4 so3_exp(V3 w) {
+  const double t2 = dot(w, w);
+  const bool small = t2 < MK_LIE_EPS;
+  const double th = sqrt(small ? 1.0 : t2);
+  double sn, cs;
+  mk_sincos(0.5 * th, &sn, &cs);
+  const double re = small ? 1.0 - t2 / 8.0 + t2 * t2 / 384.0 : cs;
+  const double im = small ? 0.5 - t2 / 48.0 + t2 * t2 / 3840.0 : sn / th;
+  return Q4{re, im * w.x, im * w.y, im * w.z};
+}
+
+// Roll, pitch, yaw of a unit quaternion (mink/lie/so3.py:116-133), i.e. the extrinsic
+// x-y-z Euler angles scipy calls as_euler("xyz").
+MK_DEV V3 quat_rpy(Q4 q) {
+  return V3{atan2(2.0 * (q.w * q.x + q.y * q.z), 1.0 - 2.0 * (q.x * q.x + q.y * q.y)),
+            asin(2.0 * (q.w * q.y - q.z * q.x)),
+            atan2(2.0 * (q.w * q.z + q.x * q.y), 1.0 - 2.0 * (q.y * q.y + q.z * q.z))};
+}
+
 struct Twist { V3 v, w; };
 
 // SE3.log (mink/lie/se3.py:159-185) of the transform (q, t).

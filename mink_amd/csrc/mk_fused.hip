@@ -330,6 +330,29 @@ MK_DEV void chain_jac(const MkFusedDesc* __restrict__ D, const double (&qc)[NC],
   cj.e = se3_log(qmul(qconj(Q), Qt), mulT(R, pt - t));
 }
 
+// World pose (Q, t) of the task frame alone: the recursion of chain_jac without columns.
+template <int NC>
+MK_DEV void chain_pose(const MkFusedDesc* __restrict__ D, const double (&qc)[NC], Q4& Q, V3& t) {
+  Q = Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]};
+  t = v3(D->post_pos[0], D->post_pos[1], D->post_pos[2]);
+  MkSegC s = D->segc[NC - 1];
+#pragma unroll
+  for (int k = NC - 1; k >= 0; --k) {
+    const MkSegC nx = D->segc[k > 0 ? k - 1 : 0];
+    double sn, cs;
+    mk_sincos(0.5 * (s.hinge * qc[k]), &sn, &cs);
+    t.z = fma(s.slide, qc[k], t.z);
+    const Q4 Qs = Q4{s.pq[0] * cs - s.pq[3] * sn, s.pq[1] * cs + s.pq[2] * sn, s.pq[2] * cs - s.pq[1] * sn,
+                     s.pq[3] * cs + s.pq[0] * sn};
+    t = qrot(Qs, t) + v3(s.pp[0], s.pp[1], s.pp[2]);
+    Q = qmul(Qs, Q);
+    MK_SCHED_FENCE();
+    MK_PIN4(Q.w, Q.x, Q.y, Q.z);
+    MK_PIN3(t.x, t.y, t.z);
+    s = nx;
+  }
+}
+
 template <int NC>
 MK_DEV void store_chain_q(const MkFusedDesc* __restrict__ D, double* row, const double (&qc)[NC]) {
 #pragma unroll
@@ -637,6 +660,114 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
   tile_copy<false>(tile, stride, q + base * nq, rows, nq);
 }
 
+// Waypoint reaching (envs/mj_env.py:193-276 with envs/robot_utils.py:113-160) as one launch:
+// per outer step the pose of the task frame, the waypoint generator (bounded linear step
+// towards the goal position, half-way slerp towards the goal orientation, reached test on
+// the position distance and the x-y-z Euler angles of goal * current^-1), then the callers'
+// IK loop towards the commanded pose.  A problem stops after the step in which its
+// generator reports the goal reached.
+template <int NC>
+__global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restrict__ D_arg, double* __restrict__ q,
+                                                    const double* __restrict__ goals, double dt, double damping,
+                                                    int B, int max_steps, int max_iters, double pos_tol,
+                                                    double ori_tol, double wp_pos_thr, double wp_pos_step,
+                                                    double wp_rot_thr, int32_t* __restrict__ steps_out,
+                                                    int32_t* __restrict__ reached_out,
+                                                    int32_t* __restrict__ solves_out,
+                                                    int32_t* __restrict__ status_out) {
+  const MkFusedDesc* D = D_arg;
+  extern __shared__ double tile[];
+  const int nq = D->nq;
+  const int stride = nq | 1;
+  const double inv_dt = 1.0 / dt;
+  const int lane = threadIdx.x;
+  const long base = (long)blockIdx.x * 64;
+  const int rows = (int)min((long)64, (long)B - base);
+  tile_copy<true>(tile, stride, q + base * nq, rows, nq);
+  __syncthreads();
+  const bool valid = lane < rows;
+  double* row = tile + lane * stride;
+  double* hlds = tile + 64 * stride + lane;
+  if (!valid) {
+    for (int i = 0; i < nq; ++i) row[i] = tile[i];
+  }
+  const long pb = valid ? base + lane : base;
+  const double* gp = goals + pb * 7;
+  const Q4 Qg = Q4{gp[0], gp[1], gp[2], gp[3]};
+  const V3 pg = v3(gp[4], gp[5], gp[6]);
+  double qc[NC], x[NC];
+  load_chain_q<NC>(D, row, qc);
+#pragma unroll
+  for (int k = 0; k < NC; ++k) x[k] = 0.0;
+  const bool sync_rows = D->any_posture_lm != 0;
+  int status = 0, steps = 0, solves = 0;
+  bool finished = false, reached = false;
+  uint32_t act = 0u, upper = 0u;
+  for (int s = 0; s < max_steps; ++s) {
+    // ---- waypoint generator on the current pose ----
+    Q4 Qt;
+    V3 pt;
+    bool now;
+    {
+      const MkFusedDesc* __restrict__ Dw = D_arg + mk_opaque_zero();
+      Q4 Qc;
+      V3 tc;
+      chain_pose<NC>(Dw, qc, Qc, tc);
+      const V3 delta = pg - tc;
+      const double dist = sqrt(dot(delta, delta));
+      const bool pos_reached = dist < wp_pos_thr;
+      const double step = fmin(dist, wp_pos_step);
+      const V3 moved = tc + (step / fmax(dist, 1e-300)) * delta;
+      pt = pos_reached ? pg : moved;
+      const V3 half = 0.5 * so3_log(qmul(qconj(Qc), Qg));
+      Qt = qmul(Qc, so3_exp(half));
+      const V3 eul = quat_rpy(qmul(Qg, qconj(Qc)));
+      now = pos_reached && sqrt(dot(eul, eul)) < wp_rot_thr;
+    }
+    // ---- the callers' IK loop towards the commanded pose ----
+    bool done = finished;
+    int iters = 0;
+    for (int it = 0; it <= max_iters; ++it) {
+      const MkFusedDesc* __restrict__ Di = D_arg + mk_opaque_zero();
+      if (!done) {
+        ChainJac<NC> cj;
+        chain_jac<NC>(Di, qc, Qt, pt, cj);
+        const bool conv = it > 0 && sqrt(dot(cj.e.v, cj.e.v)) <= pos_tol && sqrt(dot(cj.e.w, cj.e.w)) <= ori_tol;
+        if (conv || it == max_iters) {
+          done = true;
+        } else {
+          const int st = solve_problem<NC, true>(Di, row, qc, cj, dt, inv_dt, damping, x, nullptr, act, upper,
+                                                 it > 0 || s > 0, hlds, 64);
+          status = max(status, st);
+          iters = it + 1;
+#pragma unroll
+          for (int k = 0; k < NC; ++k) qc[k] = qc[k] + dt * (x[k] * inv_dt);
+          if (sync_rows) store_chain_q<NC>(Di, row, qc);
+        }
+      }
+      if (mk_wave_none(!done)) break;
+    }
+    if (!finished) {
+      ++steps;
+      solves += iters;
+      if (now) {
+        reached = true;
+        finished = true;
+      }
+    }
+    if (mk_wave_none(!finished)) break;
+  }
+  store_chain_q<NC>(D, row, qc);
+  if (valid) {
+    status_out[pb] = status;
+    if (steps_out) steps_out[pb] = steps;
+    if (reached_out) reached_out[pb] = reached ? 1 : 0;
+    if (solves_out) solves_out[pb] = solves;
+  }
+  __syncthreads();
+  tile_copy<false>(tile, stride, q + base * nq, rows, nq);
+}
+
 }  // namespace
 
 // Host-side launchers (called from mk_api.hip).
@@ -684,6 +815,35 @@ hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, do
   case N:                                                                                                  \
     return launch_iterate<N>(d_desc, nq, q, targets, target_stride, dt, damping, B, max_iters, pos_tol,   \
                              ori_tol, v, iters, err, status, stream);
+    MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
+#undef MK_CASE
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <int NC>
+static hipError_t launch_move_to(const MkFusedDesc* d_desc, int nq, double* q, const double* goals, double dt,
+                                 double damping, int B, int max_steps, int max_iters, double pos_tol, double ori_tol,
+                                 double wp_pos_thr, double wp_pos_step, double wp_rot_thr, int32_t* steps,
+                                 int32_t* reached, int32_t* solves, int32_t* status, hipStream_t stream) {
+  const int blocks = (B + 63) / 64;
+  const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
+  hipLaunchKernelGGL(fused_move_to_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, goals, dt, damping, B,
+                     max_steps, max_iters, pos_tol, ori_tol, wp_pos_thr, wp_pos_step, wp_rot_thr, steps, reached,
+                     solves, status);
+  return hipGetLastError();
+}
+
+hipError_t mk_fused_launch_move_to(int nc, const MkFusedDesc* d_desc, int nq, double* q, const double* goals,
+                                   double dt, double damping, int B, int max_steps, int max_iters, double pos_tol,
+                                   double ori_tol, double wp_pos_thr, double wp_pos_step, double wp_rot_thr,
+                                   int32_t* steps, int32_t* reached, int32_t* solves, int32_t* status,
+                                   hipStream_t stream) {
+  switch (nc) {
+#define MK_CASE(N)                                                                                              \
+  case N:                                                                                                       \
+    return launch_move_to<N>(d_desc, nq, q, goals, dt, damping, B, max_steps, max_iters, pos_tol, ori_tol,     \
+                             wp_pos_thr, wp_pos_step, wp_rot_thr, steps, reached, solves, status, stream);
     MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
 #undef MK_CASE
     default: return hipErrorInvalidValue;

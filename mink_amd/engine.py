@@ -234,6 +234,27 @@ class DeviceProblem:
         return res
 
 
+    def move_to_(self, q: torch.Tensor, goals: torch.Tensor, wp, dt: float, damping: float, max_steps: int,
+                 max_iters: int, pos_tol: float, ori_tol: float) -> dict:
+        """Waypoint reaching in one launch (``mk_move_to_batch``); q is updated in place.
+        ``wp`` has pos_threshold / pos_step_size / rot_threshold / rot_step_size.
+        Returns dict(steps, reached, solves, status) of int32 tensors [B]."""
+        B = q.shape[0]
+        _check_tensor(q, (B, self.nq), torch.float64, "q")
+        _check_tensor(goals, (B, 7), torch.float64, "goals")
+        out = {k: torch.empty((B,), dtype=torch.int32, device=self.device)
+               for k in ("steps", "reached", "solves", "status")}
+        cfg = L.WaypointConfig(float(wp.pos_threshold), float(wp.pos_step_size), float(wp.rot_threshold),
+                               float(wp.rot_step_size))
+        with torch.cuda.device(self.device):
+            L.check(self.lib.mk_move_to_batch(
+                self.handle, q.data_ptr(), goals.data_ptr(), C.byref(cfg), float(dt), float(damping), B,
+                int(max_steps), int(max_iters), float(pos_tol), float(ori_tol), out["steps"].data_ptr(),
+                out["reached"].data_ptr(), out["solves"].data_ptr(), out["status"].data_ptr(),
+                _stream_ptr(self.device)))
+        return out
+
+
 def qp_solve(P: torch.Tensor, c: torch.Tensor, G: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None):
     """Batched dense QP: min 1/2 x'Px + c'x s.t. Gx <= h. Returns (x [B, n], status [B])."""
     lib = L.load_library()

@@ -79,6 +79,42 @@ def move_to(configuration, frame_task, tasks: Sequence, target_pos, target_rot: 
     cfg = cfg or LinearWaypointReachConfig()
     dev = configuration.device
     B = configuration.batch_size
+    if not any(t is frame_task for t in tasks):
+        raise ValueError("frame_task must be one of tasks")
+    # One launch for the whole rollout when the fused kernels serve the task / limit set and
+    # the driven task is their (single) frame task; otherwise the same loop step by step.
+    from ._problems import get_problem
+    from .solve_ik import _check_solver, _resolve_limits
+    from .tasks import FrameTask
+    _check_solver(solver)
+    goal = SE3.from_rotation_and_translation(SO3(target_rot.wxyz.to(dev)),
+                                             torch.as_tensor(target_pos, dtype=torch.float64).to(dev))
+    if type(frame_task) is FrameTask:
+        saved = frame_task.transform_target_to_world
+        frame_task.transform_target_to_world = goal        # any valid pose: only its shape matters here
+        try:
+            prob, _ = get_problem(configuration, tasks, _resolve_limits(configuration, limits))
+        finally:
+            frame_task.transform_target_to_world = saved
+        if prob.fused and prob.target_stride == 7:
+            goals = goal.wxyz_xyz.to(dtype=torch.float64)
+            if goals.ndim == 1:
+                goals = goals[None, :].expand(B, -1)
+            res = prob.move_to_(configuration.q_tensor, goals.contiguous(), cfg, dt, damping, max_steps, max_iters,
+                                pos_threshold, ori_threshold)
+            assert int((res["status"] != 0).sum()) == 0, "QP solver failed (infeasible limits or non-finite input)"
+            return dict(steps=res["steps"], reached=res["reached"].bool(), solves=res["solves"].to(torch.int64))
+    return _move_to_stepwise(configuration, frame_task, tasks, target_pos, target_rot, cfg, dt, solver, damping,
+                             max_steps, max_iters, pos_threshold, ori_threshold, limits)
+
+
+def _move_to_stepwise(configuration, frame_task, tasks, target_pos, target_rot, cfg, dt, solver, damping, max_steps,
+                      max_iters, pos_threshold, ori_threshold, limits) -> dict:
+    """move_to as a host loop over outer steps (waypoint generator in torch, one iterated IK
+    launch per step): serves any task / limit set, and is the form the fused launch is
+    checked against."""
+    dev = configuration.device
+    B = configuration.batch_size
     wpr = LinearWaypointReach(torch.as_tensor(target_pos, dtype=torch.float64).to(dev),
                               SO3(target_rot.wxyz.to(dev)), cfg)
     finished = torch.zeros(B, dtype=torch.bool, device=dev)
