@@ -660,6 +660,25 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
   tile_copy<false>(tile, stride, q + base * nq, rows, nq);
 }
 
+// LinearWaypointReach.step (envs/robot_utils.py:131-160) for the current pose (Qc, tc) and
+// the goal (Qg, pg): the commanded pose (Qt, pt) -- a step of at most pos_step along the
+// straight line to the goal position (the goal itself once within pos_thr), half-way along
+// the geodesic to the goal orientation -- and whether the goal counts as reached (position
+// within pos_thr and the norm of the x-y-z Euler angles of goal * current^-1 below rot_thr).
+MK_DEV bool waypoint_step(Q4 Qc, V3 tc, Q4 Qg, V3 pg, double pos_thr, double pos_step, double rot_thr, Q4& Qt,
+                          V3& pt) {
+  const V3 delta = pg - tc;
+  const double dist = sqrt(dot(delta, delta));
+  const bool pos_reached = dist < pos_thr;
+  const double step = fmin(dist, pos_step);
+  const V3 moved = tc + (step / fmax(dist, 1e-300)) * delta;
+  pt = pos_reached ? pg : moved;
+  const V3 half = 0.5 * so3_log(qmul(qconj(Qc), Qg));
+  Qt = qmul(Qc, so3_exp(half));
+  const V3 eul = quat_rpy(qmul(Qg, qconj(Qc)));
+  return pos_reached && sqrt(dot(eul, eul)) < rot_thr;
+}
+
 // Waypoint reaching (envs/mj_env.py:193-276 with envs/robot_utils.py:113-160) as one launch:
 // per outer step the pose of the task frame, the waypoint generator (bounded linear step
 // towards the goal position, half-way slerp towards the goal orientation, reached test on
@@ -713,16 +732,7 @@ __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restric
       Q4 Qc;
       V3 tc;
       chain_pose<NC>(Dw, qc, Qc, tc);
-      const V3 delta = pg - tc;
-      const double dist = sqrt(dot(delta, delta));
-      const bool pos_reached = dist < wp_pos_thr;
-      const double step = fmin(dist, wp_pos_step);
-      const V3 moved = tc + (step / fmax(dist, 1e-300)) * delta;
-      pt = pos_reached ? pg : moved;
-      const V3 half = 0.5 * so3_log(qmul(qconj(Qc), Qg));
-      Qt = qmul(Qc, so3_exp(half));
-      const V3 eul = quat_rpy(qmul(Qg, qconj(Qc)));
-      now = pos_reached && sqrt(dot(eul, eul)) < wp_rot_thr;
+      now = waypoint_step(Qc, tc, Qg, pg, wp_pos_thr, wp_pos_step, wp_rot_thr, Qt, pt);
     }
     // ---- the callers' IK loop towards the commanded pose ----
     bool done = finished;

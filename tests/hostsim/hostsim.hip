@@ -143,6 +143,21 @@ extern "C" int hostsim_iterate(const mk_model_desc* md, const mk_task_desc* task
   HS_DISPATCH(run_iterate, D, q, targets, stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status)
 }
 
+// The device waypoint generator on B (current pose, goal pose) pairs (wxyz_xyz each):
+// commanded poses [B, 7] and reached flags [B].
+extern "C" void hostsim_waypoint_step(const double* cur, const double* goal, int B, double pos_thr, double pos_step,
+                                      double rot_thr, double* cmd, int32_t* reached) {
+  for (int b = 0; b < B; ++b) {
+    const double *c = cur + 7 * b, *g = goal + 7 * b;
+    Q4 Qt;
+    V3 pt;
+    reached[b] = waypoint_step(Q4{c[0], c[1], c[2], c[3]}, v3(c[4], c[5], c[6]), Q4{g[0], g[1], g[2], g[3]},
+                               v3(g[4], g[5], g[6]), pos_thr, pos_step, rot_thr, Qt, pt) ? 1 : 0;
+    double* o = cmd + 7 * b;
+    o[0] = Qt.w; o[1] = Qt.x; o[2] = Qt.y; o[3] = Qt.z; o[4] = pt.x; o[5] = pt.y; o[6] = pt.z;
+  }
+}
+
 // buf [B, iters, 3] receives (phase-1 rounds, phase-2 steps, single-change steps) of every solve of the next
 // hostsim_iterate calls; null switches the record off
 extern "C" void hostsim_set_trace(int32_t* buf, int iters) {

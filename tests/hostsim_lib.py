@@ -67,3 +67,16 @@ def iterate(model, task_specs, limit_specs, q, targets, dt, damping, max_iters, 
     if rc != 0:
         raise RuntimeError(f"hostsim rc={rc}: {h.mk_last_error().decode()}")
     return q, v, iters, err, status
+
+
+def waypoint_step(cur, goal, pos_thr, pos_step, rot_thr):
+    """The device waypoint generator on [B, 7] current / goal poses (wxyz_xyz)."""
+    h = _load()
+    cur = np.ascontiguousarray(cur, dtype=np.float64)
+    goal = np.ascontiguousarray(goal, dtype=np.float64)
+    B = cur.shape[0]
+    cmd = np.zeros((B, 7))
+    reached = np.zeros(B, dtype=np.int32)
+    h.hostsim_waypoint_step(_ptr(cur), _ptr(goal), C.c_int(B), C.c_double(pos_thr), C.c_double(pos_step),
+                            C.c_double(rot_thr), _ptr(cmd), _ptr(reached))
+    return cmd, reached.astype(bool)

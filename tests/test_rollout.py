@@ -47,6 +47,31 @@ def test_waypoint_step_matches_reference_code():
         assert bool(reached[b]) == done
 
 
+def test_device_waypoint_step_matches_reference_code():
+    """The waypoint generator of the one-launch kernel (host build of the same device
+    function) against the reference's step() with scipy's Rotation / Slerp."""
+    import hostsim_lib as hs
+    if not hs.available():
+        pytest.skip("host build of the device code is missing")
+    rng = np.random.default_rng(3)
+    B = 80
+    tp, te = rng.uniform(-0.5, 0.5, (B, 3)), rng.uniform(-1.5, 1.5, (B, 3))
+    cp = tp + rng.uniform(-0.2, 0.2, (B, 3)) * (rng.random((B, 1)) < 0.8)
+    ce = te + rng.uniform(-0.6, 0.6, (B, 3)) * (rng.random((B, 1)) < 0.8)
+    cp[:5], ce[:5] = tp[:5] + 1e-3, te[:5] + 1e-3
+    cp[5], ce[5] = tp[5], te[5]                                   # exactly on the goal
+    wxyz = lambda e: Rotation.from_euler("xyz", e).as_quat()[:, [3, 0, 1, 2]]
+    cmd, reached = hs.waypoint_step(np.hstack([wxyz(ce), cp]), np.hstack([wxyz(te), tp]), CFG.pos_threshold,
+                                    CFG.pos_step_size, CFG.rot_threshold)
+    assert 0 < int(reached.sum()) < B
+    for b in range(B):
+        ap, half, done = ref_step(tp[b], te[b], cp[b], ce[b], CFG)
+        np.testing.assert_allclose(cmd[b, 4:], ap, rtol=0, atol=1e-14)
+        qs = half.as_quat()[[3, 0, 1, 2]]
+        np.testing.assert_allclose(cmd[b, :4] * np.sign(cmd[b, :4] @ qs), qs, rtol=0, atol=1e-13)
+        assert bool(reached[b]) == done
+
+
 @pytest.mark.gpu
 def test_move_to_matches_sequential_reference_loop():
     import mink_amd as mink
