@@ -1,4 +1,4 @@
-// Micro-benchmark: issue cost of fp64 FMA chains at one / two / four waves per SIMD, and
+// Micro-benchmark (hipcc --offload-arch=gfx950 -O3 fma_latency.hip -o fma_latency): issue cost of fp64 FMA chains at one / two / four waves per SIMD, and
 // the shader clock the chip sustains while doing it (s_memtime ticks against the
 // constant-rate s_memrealtime).  One wave per SIMD is the occupancy of the fused IK kernels.
 #include <hip/hip_runtime.h>
