@@ -781,12 +781,23 @@ __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restric
 }  // namespace
 
 // Host-side launchers (called from mk_api.hip).
+// Dynamic LDS beyond the 64 KB default needs the kernel's limit raised (long q rows with a
+// 12-dof chain); the CU has 160 KB.
+template <class K>
+static hipError_t allow_lds(K kernel, size_t lds) {
+  if (lds <= 64 * 1024) return hipSuccess;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)lds);
+}
+
 template <int NC>
 static hipError_t launch_step(const MkFusedDesc* d_desc, int nq, const double* q, const double* targets,
                               int target_stride, double dt, double damping, int B, double* v, int32_t* status,
                               hipStream_t stream) {
   const int blocks = (B + 63) / 64;
   const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
+  if (hipError_t e = allow_lds(fused_step_kernel<NC>, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(fused_step_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, targets, target_stride,
                      dt, damping, B, v, status);
   return hipGetLastError();
@@ -799,6 +810,7 @@ static hipError_t launch_iterate(const MkFusedDesc* d_desc, int nq, double* q, c
                                  hipStream_t stream) {
   const int blocks = (B + 63) / 64;
   const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
+  if (hipError_t e = allow_lds(fused_iterate_kernel<NC>, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(fused_iterate_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
                      target_stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status);
   return hipGetLastError();
@@ -838,6 +850,7 @@ static hipError_t launch_move_to(const MkFusedDesc* d_desc, int nq, double* q, c
                                  int32_t* reached, int32_t* solves, int32_t* status, hipStream_t stream) {
   const int blocks = (B + 63) / 64;
   const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
+  if (hipError_t e = allow_lds(fused_move_to_kernel<NC>, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(fused_move_to_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, goals, dt, damping, B,
                      max_steps, max_iters, pos_tol, ori_tol, wp_pos_thr, wp_pos_step, wp_rot_thr, steps, reached,
                      solves, status);
