@@ -469,8 +469,8 @@ bool build_dense(const HostModel& m, const mk_task_desc* tasks, int ntask, const
         if (t1 > t2) std::swap(t1, t2);
         // MuJoCo geom types: plane 0, sphere 2, capsule 3, box 6
         const bool ok = (t1 == 0 && (t2 == 2 || t2 == 3 || t2 == 6)) || (t1 == 2 && (t2 == 2 || t2 == 3 || t2 == 6)) ||
-                        (t1 == 3 && t2 == 3) || (t1 == 6 && t2 == 6);
-        if (!ok) { why = "geom pair types without a distance routine (supported: plane-{sphere,capsule,box}, sphere-{sphere,capsule,box}, capsule-capsule, box-box)"; return false; }
+                        (t1 == 3 && (t2 == 3 || t2 == 6)) || (t1 == 6 && t2 == 6);
+        if (!ok) { why = "geom pair types without a distance routine (supported: plane-{sphere,capsule,box}, sphere-{sphere,capsule,box}, capsule-{capsule,box}, box-box)"; return false; }
       }
       O.n = L.n;
       O.gain = L.gain;

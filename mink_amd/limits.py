@@ -137,7 +137,7 @@ def _allowed(model, a: int, b: int) -> bool:
 
 class CollisionAvoidanceLimit(Limit):
     """Normal-velocity limit between geom pairs (mink/limits/collision_avoidance_limit.py).
-    Distances are available for plane / sphere / box primitives."""
+    Distances are available between plane, sphere, capsule and box primitives."""
 
     def __init__(self, model, geom_pairs: Sequence, gain: float = 0.85,
                  minimum_distance_from_collisions: float = 0.005, collision_detection_distance: float = 0.01,

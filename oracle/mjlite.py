@@ -439,6 +439,53 @@ def _closest_box_box(c1, r1, h1, c2, r2, h2):
     return math.sqrt(best), p1, p2
 
 
+def _capsule_box(c1, r1, s1, c2, r2, h2):
+    """Signed distance and witness points of a capsule (radius s1[0], half length s1[1]
+    along its z axis) and an oriented box.
+
+    Axis segment outside the box: exact closest points of the segment and the box -- the two
+    end points against the box, then the segment against the 12 box edges, in this fixed
+    order, first strict minimum wins -- and dist = that distance - radius.  Axis segment
+    through the box: the point in the middle of the part inside the box leaves through its
+    nearest face (the rule of sphere-box for a centre inside), dist = -(gap + radius)."""
+    ax = r1[:, 2]
+    a, b = c1 - ax * s1[1], c1 + ax * s1[1]
+    best, u, w = np.inf, None, None
+    for e in (a, b):
+        pb = _point_box(e, c2, r2, h2)
+        dd = float((e - pb) @ (e - pb))
+        if dd < best:
+            best, u, w = dd, e, pb
+    for (b0, b1) in _box_edges(c2, r2, h2):
+        x, y = _seg_seg(a, b, b0, b1)
+        dd = float((x - y) @ (x - y))
+        if dd < best:
+            best, u, w = dd, x, y
+    # does the segment pass through the box? clip it against the three slabs
+    la, ld = r2.T @ (a - c2), r2.T @ (b - a)
+    t0, t1 = 0.0, 1.0
+    for k in range(3):
+        if abs(ld[k]) < 1e-300:
+            if abs(la[k]) > h2[k]:
+                t0, t1 = 1.0, 0.0
+                break
+        else:
+            ta, tb = (-h2[k] - la[k]) / ld[k], (h2[k] - la[k]) / ld[k]
+            t0, t1 = max(t0, min(ta, tb)), min(t1, max(ta, tb))
+    if t0 <= t1:
+        loc = la + 0.5 * (t0 + t1) * ld
+        gap = h2 - np.abs(loc)
+        k = int(np.argmin(gap))
+        sgn = 1.0 if loc[k] >= 0 else -1.0
+        axis = r2[:, k] * sgn
+        face = loc.copy()
+        face[k] = sgn * h2[k]
+        mid = c2 + r2 @ loc
+        return -float(gap[k]) - s1[0], mid - s1[0] * axis, c2 + r2 @ face
+    axis, nrm = mju_normalize3(w - u)
+    return nrm - s1[0], u + s1[0] * axis, w
+
+
 def _sphere_sphere(c1, r1, c2, r2):
     axis, nrm = mju_normalize3(c2 - c1)
     return nrm - r1 - r2, c1 + r1 * axis, c2 - r2 * axis
@@ -448,9 +495,9 @@ def mj_geomDistance(m, d, g1, g2, distmax):
     """Smallest signed distance between two primitive geoms, and the segment
     (fromto) joining the closest points, or (distmax, zeros) when farther than
     distmax.  Supported pairs: plane-{sphere, capsule, box}, sphere-{sphere, capsule, box},
-    capsule-capsule, box-box.
-    PARITY UNPINNED: MuJoCo's box-box routine is not restated; the Euclidean
-    closest-point distance is used instead."""
+    capsule-{capsule, box}, box-box.
+    PARITY UNPINNED: MuJoCo's box-box and capsule-box routines are not restated; the
+    Euclidean closest-point distance is used instead."""
     t1, t2 = m.geom_type[g1], m.geom_type[g2]
     fromto = np.zeros(6)
     swap = False
@@ -513,6 +560,8 @@ def mj_geomDistance(m, d, g1, g2, distmax):
             face[k] = sgn * s2[k]
             p2 = c2 + r2 @ face
             p1 = c1 - s1[0] * axis
+    elif t1 == GEOM_CAPSULE and t2 == GEOM_BOX:
+        dist, p1, p2 = _capsule_box(c1, r1, s1, c2, r2, s2)
     elif t1 == GEOM_BOX and t2 == GEOM_BOX:
         dist, p1, p2 = _closest_box_box(c1, r1, s1, c2, r2, s2)
     else:

@@ -248,7 +248,8 @@ def test_gpu_floating_base_tree_vs_oracle(fmodel):
 
 PRIM_PAIRS = [("obj_geom", "shin_geom"), ("shin_geom", "bar_geom"), ("ground", "shin_geom"), ("obj_geom", "torso_geom"),
               ("obj_geom", "fore_geom"), ("leg_geom", "obj_geom"), ("ground", "fore_geom"), ("torso_geom", "fore_geom"),
-              ("upper_geom", "bar_geom"), ("ground", "obj_geom")]
+              ("upper_geom", "bar_geom"), ("ground", "obj_geom"), ("shin_geom", "fore_geom"), ("bar_geom", "torso_geom"),
+              ("bar_geom", "fore_geom")]
 
 
 def near_configuration(model, rng, pair):
