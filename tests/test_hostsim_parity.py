@@ -126,3 +126,25 @@ def test_padding_and_other_model(golden_dir):
         ref = o.solve_ik(cfg, tasks, W.DT, damping=W.DAMPING,
                          limits=[o.ConfigurationLimit(model), o.VelocityLimit(model, W.VELOCITY_LIMITS)])
         np.testing.assert_allclose(v[b], ref, rtol=0, atol=1e-9)
+
+
+def test_cabinet_scene_model():
+    """tidybot_open (the reference's open.xml: nq = nv = 20, two limited cabinet door hinges
+    beside the robot, no free joint): fused path of the host build against the oracle."""
+    from oracle import ik_oracle as o
+    model = load_builtin("tidybot_open")
+    assert model.nq == 20 and model.nv == 20
+    rng = np.random.default_rng(9)
+    B = 30
+    q, qs = W.sample_q(model, rng, B), W.sample_q(model, rng, B)
+    q[:, 18:] = rng.uniform(0.0, 0.5, (B, 2))      # doors ajar
+    targets = np.array([o.Configuration(model, x).get_transform_frame_to_world("pinch_site", "site") for x in qs])
+    v, st = hs.solve_ik(model, W.task_specs(model, True), W.limit_specs(model, True), q, targets, W.DT, W.DAMPING)
+    assert not st.any()
+    for b in range(B):
+        tasks = [o.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0, target=targets[b]),
+                 o.PostureTask(cost=W.posture_cost(model), target_q=W.home_q(model)),
+                 o.DampingTask(model, W.base_damping_cost(model))]
+        ref = o.solve_ik(o.Configuration(model, q[b]), tasks, W.DT, damping=W.DAMPING,
+                         limits=[o.ConfigurationLimit(model), o.VelocityLimit(model, W.VELOCITY_LIMITS)])
+        np.testing.assert_allclose(v[b], ref, rtol=0, atol=1e-9)
