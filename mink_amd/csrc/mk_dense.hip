@@ -1004,8 +1004,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MK_DENSE_WPE
   const bool own = lane < n;
   for (long b = blockIdx.x; b < B; b += gridDim.x) {
     // ---- inputs, kinematics ----
-    for (int i = lane; i < m.nq; i += 64) s.q[i] = q[b * m.nq + i];
-    for (int i = lane; i < target_stride; i += 64) s.tg[i] = targets[b * target_stride + i];
+    bool bad_lane = false;
+    for (int i = lane; i < m.nq; i += 64) {
+      const double qv = q[b * m.nq + i];
+      bad_lane |= !(fabs(qv) < INFINITY);
+      s.q[i] = qv;
+    }
+    for (int i = lane; i < target_stride; i += 64) {
+      const double tv = targets[b * target_stride + i];
+      bad_lane |= !(fabs(tv) < INFINITY);
+      s.tg[i] = tv;
+    }
+    const bool input_bad = __ballot(bad_lane) != 0ull;
     for (int idx = lane; idx < n * np; idx += 64) s.P[idx] = 0.0;
     if (own) { s.c[lane] = 0.0; s.dkind[lane] = MK_COL_LIN; }
     for (int i = lane; i < 3 * n; i += 64) { s.daxis[i] = 0.0; s.danch[i] = 0.0; }
@@ -1297,8 +1307,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MK_DENSE_WPE
     continue;
 #endif
     if (v_out) {
-      double x;
-      const int st = gi_solve(s, n, mg, lane, lo, hi, x);
+      double x = 0.0;
+      int st = gi_solve(s, n, mg, lane, lo, hi, x);
+      // non-finite input shows up as a failed factorisation or a non-finite solution:
+      // status 3 and a zero velocity for the whole problem
+      if (input_bad || st == 3 || __ballot(own && !(fabs(x) < INFINITY)) != 0ull) {
+        st = 3;
+        x = 0.0;
+      }
       if (own) v_out[b * n + lane] = x / dt;
       if (lane == 0) status_out[b] = st;
     }

@@ -371,6 +371,17 @@ MK_DEV void load_chain_q(const MkFusedDesc* __restrict__ D, const double* row, d
   }
 }
 
+// True when a coordinate outside the chain (scalar dofs, free-joint poses) is not finite.
+// Those coordinates only change by the kernels' own finite updates, so one look per launch
+// is enough.
+MK_DEV bool rest_nonfinite(const MkFusedDesc* __restrict__ D, const double* row) {
+  double acc = 0.0;
+  for (int d = 0; d < D->nd; ++d) acc += 0.0 * row[D->ddof[d].qadr];
+  for (int f = 0; f < D->nfree; ++f)
+    for (int k = 0; k < 7; ++k) acc += 0.0 * row[D->free_qadr[f] + k];
+  return !(acc == 0.0);
+}
+
 // Builds and solves the QP of one problem from its chain kinematics. `row` is the
 // lane's q row in LDS. On return x holds dq of the chain dofs; the other dofs are
 // handled in place:
@@ -381,7 +392,7 @@ template <int NC, bool INTEGRATE>
 MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const double (&qc)[NC],
                          ChainJac<NC>& cj, double dt, double inv_dt, double damping, double (&x)[NC],
                          double* vrow, uint32_t& act, uint32_t& upper, bool warm, double* hstore,
-                         int hstride) {
+                         int hstride, bool input_bad = false) {
   const Twist e = cj.e;
   M3 Ji, Bm;
   se3_ljacinv_blocks(e, Ji, Bm);
@@ -470,7 +481,8 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
 #endif
   {
     // non-finite chain q or target: the task error, hence every entry of c, is NaN
-    if (!(fabs(diag + c[0]) < INFINITY)) {
+    // (input_bad: a non-finite coordinate outside the chain, found by the caller)
+    if (input_bad || !(fabs(diag + c[0]) < INFINITY)) {
       status = 3;
 #pragma unroll
       for (int i = 0; i < NC; ++i) x[i] = 0.0;
@@ -481,6 +493,13 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
   // (the constants of the next dof are fetched while the current one is computed)
   const int nd = D->nd;
   dc = D->ddof[0];
+  if (status == 3) {
+    // flagged problem: nothing moves (rare, so the common path pays one branch)
+    for (int d = 0; d < nd; ++d) {
+      const MkDofC z = D->ddof[d];
+      if (!INTEGRATE) row[z.dof] = 0.0; else if (vrow) vrow[z.dof] = 0.0;
+    }
+  } else
   for (int d = 0; d < nd; ++d) {
     const MkDofC nx = D->ddof[d + 1 < MK_MAX_NV ? d + 1 : d];
     const double qi = row[dc.qadr];
@@ -561,7 +580,7 @@ __global__ MK_KERNEL_ATTR void fused_step_kernel(const MkFusedDesc* __restrict__
   chain_jac<NC>(D, qc, Qt, pt, cj);
   uint32_t act = 0u, upper = 0u;
   int status = solve_problem<NC, false>(D, row, qc, cj, dt, inv_dt, damping, x, nullptr, act, upper, false,
-                                        hlds, 64);
+                                        hlds, 64, rest_nonfinite(D, row));
 #pragma unroll
   for (int k = 0; k < NC; ++k)
     if (D->seg_dof[k] >= 0) row[D->seg_dof[k]] = x[k] * inv_dt;
@@ -604,6 +623,7 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
 #pragma unroll
   for (int k = 0; k < NC; ++k) x[k] = 0.0;
   const bool sync_rows = D->any_posture_lm != 0;   // only that path reads chain q from the rows
+  const bool input_bad = rest_nonfinite(D, row);
   Twist e = Twist{v3(0, 0, 0), v3(0, 0, 0)};
   int status = 0, iters = 0;
   bool done = false;
@@ -627,7 +647,8 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
 #pragma unroll
         for (int k = 0; k < NC; ++k) x[k] = 1e-4 * (cj.e.v.x + cj.e.w.y + cj.J[0][k] + cj.J[4][k]);
 #else
-        int st = solve_problem<NC, true>(D, row, qc, cj, dt, inv_dt, damping, x, vrow, act, upper, it > 0, hlds, 64);
+        int st = solve_problem<NC, true>(D, row, qc, cj, dt, inv_dt, damping, x, vrow, act, upper, it > 0, hlds, 64,
+                                         input_bad);
 #endif
         status = max(status, st);
         iters = it + 1;
@@ -719,6 +740,7 @@ __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restric
 #pragma unroll
   for (int k = 0; k < NC; ++k) x[k] = 0.0;
   const bool sync_rows = D->any_posture_lm != 0;
+  const bool input_bad = rest_nonfinite(D, row);
   int status = 0, steps = 0, solves = 0;
   bool finished = false, reached = false;
   uint32_t act = 0u, upper = 0u;
@@ -747,7 +769,7 @@ __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restric
           done = true;
         } else {
           const int st = solve_problem<NC, true>(Di, row, qc, cj, dt, inv_dt, damping, x, nullptr, act, upper,
-                                                 it > 0 || s > 0, hlds, 64);
+                                                 it > 0 || s > 0, hlds, 64, input_bad);
           status = max(status, st);
           iters = it + 1;
 #pragma unroll

@@ -28,7 +28,8 @@ int run_step(const MkFusedDesc& D, const double* q, const double* targets, int s
     ChainJac<NC> fk;
     chain_jac<NC>(&D, qc, Q4{tg[0], tg[1], tg[2], tg[3]}, v3(tg[4], tg[5], tg[6]), fk);
     uint32_t act = 0u, upper = 0u;
-    status[b] = solve_problem<NC, false>(&D, row.data(), qc, fk, dt, 1.0 / dt, damping, x, nullptr, act, upper, false, hbuf, 1);
+    status[b] = solve_problem<NC, false>(&D, row.data(), qc, fk, dt, 1.0 / dt, damping, x, nullptr, act, upper, false, hbuf, 1,
+                                         rest_nonfinite(&D, row.data()));
     for (int k = 0; k < NC; ++k)
       if (D.seg_dof[k] >= 0) row[D.seg_dof[k]] = x[k] * (1.0 / dt);
     memcpy(v + (size_t)b * D.nv, row.data(), D.nv * sizeof(double));
@@ -54,6 +55,7 @@ int run_iterate(const MkFusedDesc& D, double* q, const double* targets, int stri
     Twist e{};
     int status = 0, iters = 0;
     uint32_t act = 0u, upper = 0u;
+    const bool input_bad = rest_nonfinite(&D, row.data());
     for (int it = 0; it <= max_iters; ++it) {
       ChainJac<NC> fk;
       chain_jac<NC>(&D, qc, Qt, pt, fk);
@@ -63,7 +65,8 @@ int run_iterate(const MkFusedDesc& D, double* q, const double* targets, int stri
 #if !defined(__HIP_DEVICE_COMPILE__)
       const long r0 = g_qp_stats[1], p0 = g_qp_stats[2], s0 = g_qp_stats[4];
 #endif
-      int st = solve_problem<NC, true>(&D, row.data(), qc, fk, dt, 1.0 / dt, damping, x, vrow, act, upper, it > 0, hbuf, 1);
+      int st = solve_problem<NC, true>(&D, row.data(), qc, fk, dt, 1.0 / dt, damping, x, vrow, act, upper, it > 0, hbuf, 1,
+                                       input_bad);
 #if !defined(__HIP_DEVICE_COMPILE__)
       if (g_trace && it < g_trace_iters) {
         int32_t* tr = g_trace + ((size_t)b * g_trace_iters + it) * 3;
