@@ -313,3 +313,46 @@ def test_iterated_loop_on_the_general_path(model):
         np.testing.assert_allclose(res["err"][b].cpu().numpy(), e, rtol=0, atol=1e-10)
         np.testing.assert_allclose(res["v"][b].cpu().numpy(), v, rtol=0, atol=1e-8)
     assert iters.min() < max_iters and iters.max() == max_iters
+
+
+def test_reference_solve_ik_cases(model):
+    """The cases of the reference's tests/test_solve_ik.py:62-148 on TidyBot: no limits ->
+    no inequality rows; default limits; no task -> zero velocity; a fulfilled task -> zero
+    velocity; a single FrameTask converges monotonically in fewer than 20 steps at the API's
+    default damping (1e-12)."""
+    from numpy.linalg import norm
+    cfg = mink.Configuration(model)
+    cfg.update_from_keyframe("home")
+    limits = [mink.ConfigurationLimit(model)]
+    problem = mink.build_ik(cfg, [], limits=[], dt=1.0)
+    assert problem.G is None and problem.h is None
+    problem = mink.build_ik(cfg, [], dt=1.0)
+    assert problem.G is not None and problem.h is not None
+    v = mink.solve_ik(cfg, [], limits=[], dt=1e-3, solver="quadprog")
+    np.testing.assert_allclose(v, np.zeros(model.nv))
+    task = mink.FrameTask("pinch_site", "site", position_cost=1.0, orientation_cost=1.0)
+    task.set_target(cfg.get_transform_frame_to_world("pinch_site", "site"))
+    v = mink.solve_ik(cfg, [task], limits=limits, dt=1e-3, solver="quadprog")
+    np.testing.assert_allclose(v, np.zeros(model.nv), atol=1e-10)
+    # convergence
+    T0 = cfg.get_transform_frame_to_world("pinch_site", "site")
+    target = T0 @ mink.SE3.from_translation(np.array([0.0, 0.0, 0.1]))
+    task.set_target(target)
+    dt = 5e-3
+    velocity = mink.solve_ik(cfg, [task], limits=limits, dt=dt, solver="quadprog")
+    assert not np.allclose(velocity, 0.0)
+    assert abs(norm(task.compute_error(cfg)) - 0.1) < 1e-7
+    last_error = 1e6
+    for nb_steps in range(50):
+        error = norm(task.compute_error(cfg))
+        if error < 1e-6 and np.allclose(velocity, 0.0):
+            break
+        assert error < last_error
+        last_error = error
+        cfg.integrate_inplace(velocity, dt)
+        velocity = mink.solve_ik(cfg, [task], limits=limits, dt=dt, solver="quadprog")
+    assert np.allclose(velocity, 0.0)
+    assert norm(task.compute_error(cfg)) < 1e-7
+    np.testing.assert_allclose(cfg.get_transform_frame_to_world("pinch_site", "site").as_matrix().numpy(),
+                               target.as_matrix().numpy(), atol=1e-7)
+    assert nb_steps < 20
