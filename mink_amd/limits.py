@@ -32,6 +32,11 @@ class Limit:
         from ._problems import _signature
         return _signature(self._spec(model))
 
+    def _is_custom(self) -> bool:
+        """True for a subclass that brings its own compute_qp_inequalities instead of a
+        descriptor the kernels evaluate (the Limit seam of mink/limits/limit.py:11-57)."""
+        return type(self)._spec is Limit._spec
+
     def compute_qp_inequalities(self, configuration, dt: float) -> Constraint:
         from ._problems import get_problem
         spec = self._spec(configuration.model)

@@ -35,12 +35,57 @@ def _resolve_limits(configuration, limits):
     return limits
 
 
+def _has_custom(tasks, limits) -> bool:
+    return any(t._is_custom() for t in tasks) or any(l._is_custom() for l in limits)
+
+
+def _assemble_with_custom(configuration, tasks, limits, dt, damping):
+    """Dense (P, c, G, h) device tensors when some tasks / limits are user-defined subclasses:
+    the built-in ones are assembled by the kernels (mk_build_qp_batch), the others add their
+    objective (generic formula on their compute_error / compute_jacobian) and their rows."""
+    dev, B = configuration.device, configuration.batch_size
+    builtin_t = [t for t in tasks if not t._is_custom()]
+    builtin_l = [l for l in limits if not l._is_custom()]
+    prob, targets = get_problem(configuration, builtin_t, builtin_l)
+    P, c, G, h = prob.build_qp(configuration.q_tensor, targets, dt, damping)
+    for t in tasks:
+        if t._is_custom():
+            H_t, c_t = t._generic_objective(configuration)
+            P = P + H_t
+            c = c + c_t
+    rows_G, rows_h = ([G], [h]) if G is not None else ([], [])
+    for l in limits:
+        if not l._is_custom():
+            continue
+        con = l.compute_qp_inequalities(configuration, dt)
+        if con.inactive:
+            continue
+        Gl = torch.as_tensor(con.G, dtype=torch.float64).to(dev)
+        hl = torch.as_tensor(con.h, dtype=torch.float64).to(dev)
+        if Gl.ndim == 2:
+            Gl, hl = Gl[None].expand(B, -1, -1), hl[None].expand(B, -1)
+        if Gl.shape[0] != B or Gl.shape[2] != prob.nv or tuple(hl.shape) != tuple(Gl.shape[:2]):
+            raise ValueError(f"{l.__class__.__name__}: compute_qp_inequalities must return G [.., m, {prob.nv}] and "
+                             f"h [.., m] for {B} configuration(s)")
+        rows_G.append(Gl)
+        rows_h.append(hl)
+    if rows_G:
+        G, h = torch.cat(rows_G, dim=1).contiguous(), torch.cat(rows_h, dim=1).contiguous()
+    else:
+        G = h = None
+    return P.contiguous(), c.contiguous(), G, h
+
+
 def build_ik(configuration, tasks: Sequence[Task], dt: float, damping: float = 1e-12,
              limits: Optional[Sequence[Limit]] = None) -> Problem:
     """Build the QP of the current configuration(s). ``limits=None`` means a default
     ConfigurationLimit, ``limits=[]`` no limits (G and h are None)."""
-    prob, targets = get_problem(configuration, tasks, _resolve_limits(configuration, limits))
-    P, c, G, h = prob.build_qp(configuration.q_tensor, targets, dt, damping)
+    limits = _resolve_limits(configuration, limits)
+    if _has_custom(tasks, limits):
+        P, c, G, h = _assemble_with_custom(configuration, tasks, limits, dt, damping)
+    else:
+        prob, targets = get_problem(configuration, tasks, limits)
+        P, c, G, h = prob.build_qp(configuration.q_tensor, targets, dt, damping)
     o = configuration._out
     return Problem(o(P), o(c), None if G is None else o(G), None if h is None else o(h))
 
@@ -56,6 +101,16 @@ def solve_ik(configuration, tasks: Sequence[Task], dt: float, solver: str, dampi
     """Velocity ``v`` tangent to the current configuration(s): [nv] numpy for a single
     configuration, [B, nv] device tensor for a batch."""
     _check_solver(solver)
+    limits = _resolve_limits(configuration, limits)
+    if _has_custom(tasks, limits):
+        # user-defined Task / Limit subclasses: assemble the dense QP and hand it to the
+        # batched QP kernel (mk_qp_solve_batch)
+        from .engine import qp_solve
+        configuration.check_limits(safety_break=safety_break)
+        P, c, G, h = _assemble_with_custom(configuration, tasks, limits, dt, damping)
+        x, status = qp_solve(P, c, G, h)
+        assert int((status != 0).sum()) == 0, "QP solver failed (infeasible limits or non-finite input)"
+        return configuration._out(x / dt)
     if not configuration.batched:
         # One configuration: the limit check rides along with the solve and one copy brings
         # back velocity, solver status and the check's result.
@@ -83,6 +138,9 @@ def solve_ik_iterate(configuration, tasks: Sequence[Task], dt: float, solver: st
     limit set runs the same loop as a sequence of launches of the general kernels, with the
     exit test on its first FrameTask."""
     _check_solver(solver)
+    if _has_custom(tasks, _resolve_limits(configuration, limits)):
+        raise NotImplementedError("solve_ik_iterate runs built-in tasks and limits only; with user-defined Task / "
+                                  "Limit subclasses call solve_ik and integrate_inplace step by step")
     prob, targets = get_problem(configuration, tasks, _resolve_limits(configuration, limits))
     if not prob.fused:
         res = _iterate_general(configuration, prob, targets, tasks, dt, damping, max_iters, pos_threshold,

@@ -76,9 +76,45 @@ class Task:
         return configuration._out(jac)
 
     def compute_qp_objective(self, configuration) -> Objective:
+        if self._is_custom():
+            H, c = self._generic_objective(configuration)
+            return Objective(configuration._out(H), configuration._out(c))
         prob, targets = self._problem(configuration)
         P, c, _, _ = prob.build_qp(configuration.q_tensor, targets, 1.0, 0.0)
         return Objective(configuration._out(P), configuration._out(c))
+
+    # -- user-defined tasks ----------------------------------------------------
+    def _is_custom(self) -> bool:
+        """True for a subclass that brings its own compute_error / compute_jacobian instead
+        of a descriptor the kernels evaluate (the Task seam of mink/tasks/task.py:81-103)."""
+        return type(self)._spec is Task._spec
+
+    def _generic_objective(self, configuration):
+        """(H [B, nv, nv], c [B, nv]) device tensors from the subclass's error e [.., k] and
+        Jacobian J [.., k, nv] (numpy or tensors, with or without the batch axis), by the
+        formula of mink/tasks/task.py:105-138: Jw = diag(cost) J, ew = diag(cost)(-gain e),
+        H = Jw'Jw + lm_damping |ew|^2 I, c = -ew'Jw."""
+        dev, B, nv = configuration.device, configuration.batch_size, configuration.model.nv
+
+        def dev_t(a, tail):
+            t = torch.as_tensor(a, dtype=torch.float64).to(dev)
+            if t.ndim == tail:
+                t = t[None].expand((B,) + tuple(t.shape))
+            return t
+
+        J = dev_t(self.compute_jacobian(configuration), 2)
+        e = dev_t(self.compute_error(configuration), 1)
+        if J.shape[0] != B or e.shape[0] != B or J.shape[2] != nv or J.shape[1] != e.shape[1]:
+            raise TaskDefinitionError(f"{self.__class__.__name__}: compute_error / compute_jacobian must return "
+                                      f"[.., k] and [.., k, {nv}] for {B} configuration(s)")
+        cost = torch.as_tensor(np.broadcast_to(np.atleast_1d(self.cost), (e.shape[1],)).copy(),
+                               dtype=torch.float64).to(dev)
+        Jw = cost[None, :, None] * J
+        ew = cost[None, :] * (-self.gain * e)
+        mu = self.lm_damping * (ew * ew).sum(dim=1)
+        H = Jw.transpose(1, 2) @ Jw + mu[:, None, None] * torch.eye(nv, dtype=torch.float64, device=dev)
+        c = -torch.einsum("bk,bkn->bn", ew, Jw)
+        return H, c
 
 
 def _pose_target(task, pose: SE3, configuration) -> torch.Tensor:
