@@ -252,6 +252,10 @@ PRIM_PAIRS = [("obj_geom", "shin_geom"), ("shin_geom", "bar_geom"), ("ground", "
               ("bar_geom", "fore_geom")]
 
 
+CAPSULE_BOX_PAIRS = [("shin_geom", "fore_geom"), ("bar_geom", "torso_geom"), ("bar_geom", "fore_geom")]
+CAPSULE_RADIUS = {"shin_geom": 0.03, "bar_geom": 0.02}
+
+
 def near_configuration(model, rng, pair):
     """A random configuration with the free object moved next to one geom of `pair`."""
     q = random_q(model, rng)
@@ -269,7 +273,7 @@ def near_configuration(model, rng, pair):
 def test_primitive_distance_gradient_matches_contact_row(fmodel, pair):
     """d(dist)/dq by finite differences equals n'(Jp2 - Jp1) at the witness points: checks
     distance, witness points and the normal of every primitive routine together."""
-    rng = np.random.default_rng(abs(hash(pair)) % 1000)
+    rng = np.random.default_rng(100 + PRIM_PAIRS.index(pair))
     g1, g2 = fmodel.geom_id(pair[0]), fmodel.geom_id(pair[1])
     eps, checked = 1e-7, 0
     for _ in range(12):
@@ -297,6 +301,8 @@ def test_primitive_distance_gradient_matches_contact_row(fmodel, pair):
             grad[i] = (dp - dm) / (2 * eps)
         if pair == ("torso_geom", "fore_geom") and d0 < 0:
             continue         # overlapping boxes report a penetration depth, not a smooth distance
+        if pair in CAPSULE_BOX_PAIRS and d0 < -CAPSULE_RADIUS[pair[0]]:
+            continue         # capsule axis through the box: a face-exit depth, not a smooth distance either
         np.testing.assert_allclose(row, grad, rtol=0, atol=2e-5)
         checked += 1
     assert checked >= 3
