@@ -112,8 +112,9 @@ MK_DEV void symv(HView H, const double (&x)[N], double (&y)[N]) {
 // Active-set method on lane masks, exact for strictly convex problems.  An "S-pair" is
 // an active set A with x the minimiser on the face {x_A at its bounds} and multipliers
 // u_A >= 0.
-//   phase 1  starts from a guess of A ({} cold, or the active set of the previous IK
-//            step of the same problem when warm) and repeats: solve on the face, drop
+//   phase 1  starts from a guess of A (cold: the bounds violated by the diagonal estimate
+//            -c_i / H_ii; warm: the active set of the previous IK step of the same
+//            problem) and repeats: solve on the face, drop
 //            every bound whose multiplier is negative and (for the first few rounds)
 //            add every violated bound.  A round that changes nothing has found the
 //            optimum outright.  After kGuessRounds (3 warm, 6 cold) the additions stop, so the set only
@@ -145,6 +146,16 @@ MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const do
     for (int i = 0; i < N; ++i) {
       const double b = ((upper >> i) & 1u) ? hi[i] : lo[i];
       if (!(fabs(b) < INFINITY)) act &= ~(1u << i);
+    }
+  }
+  if (!warm) {
+    // cold start: the guess is the set of bounds that the diagonal estimate -c_i / H_ii
+    // violates (about half the rounds of starting from the empty set)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const double xi = -c[i] * mk_rcp(H(tri(i, i)));
+      if (xi > hi[i]) { act |= (1u << i); upper |= (1u << i); }
+      if (xi < lo[i]) { act |= (1u << i); upper &= ~(1u << i); }
     }
   }
   // ---- phase 1 ----
