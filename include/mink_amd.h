@@ -151,7 +151,10 @@ int mk_solve_ik_batch(const mk_problem* problem, const double* d_q, const double
  * |e[:3]| <= pos_tol and |e[3:]| <= ori_tol (pass negative tolerances to run
  * exactly max_iters solves).  d_q is updated in place; optional outputs (may be
  * NULL): d_v last velocity [B, nv], d_iters solves executed [B], d_err final
- * frame-task error [B, 6]. */
+ * frame-task error [B, 6].  Problems of the fused path run the loop in one launch;
+ * for any other task / limit set the same loop is issued as launches of the general
+ * kernels (error, solve, integrate per pass, finished problems skipped), and d_v,
+ * d_iters and d_err are then required: they hold the state of the loop. */
 int mk_solve_ik_iterate_batch(const mk_problem* problem, double* d_q, const double* d_targets,
                               double dt, double damping, int32_t B, int32_t max_iters,
                               double pos_tol, double ori_tol, double* d_v, int32_t* d_iters,

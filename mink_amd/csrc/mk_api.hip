@@ -801,7 +801,40 @@ int mk_solve_ik_iterate_batch(const mk_problem* p, double* d_q, const double* d_
   MK_ON_DEVICE(p->model);
   if (!d_q || !d_status) return fail(MK_ERR_INVALID, "null argument");
   if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
-  if (!p->fused) return fail(MK_ERR_UNSUPPORTED, "the iterated solve needs a problem the fused path serves");
+  if (!p->fused) {
+    // General path: the same loop as a sequence of launches of the wave-per-problem kernels.
+    // The optional outputs double as the loop's state (no device memory is allocated):
+    // `iters` carries a done bit while the loop runs, `err` the latest frame-task error,
+    // `v` the velocity of each problem's last solve.  Problems that have left the loop are
+    // skipped by every later launch; nothing synchronises, so all max_iters passes are
+    // issued.
+    if (!p->dense) return fail(MK_ERR_UNSUPPORTED, "dense path unavailable: %s", p->dense_why.c_str());
+    if (!d_v || !d_iters || !d_err)
+      return fail(MK_ERR_INVALID, "outside the fused path d_v, d_iters and d_err hold the state of the loop and must be given");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int frame_k = -1;
+    for (int t = 0; t < p->h_dense.ntask && frame_k < 0; ++t)
+      if (p->h_dense.task[t].type == MK_TASK_FRAME) frame_k = t;
+    const int nv = p->info.nv;
+    MK_HIP(hipMemsetAsync(d_iters, 0, sizeof(int32_t) * (size_t)B, st));
+    MK_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * (size_t)B, st));
+    MK_HIP(hipMemsetAsync(d_v, 0, sizeof(double) * (size_t)B * nv, st));
+    MK_HIP(hipMemsetAsync(d_err, 0, sizeof(double) * (size_t)B * 6, st));
+    for (int it = 0; it <= max_iters; ++it) {
+      if (frame_k >= 0)
+        MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets,
+                               p->info.target_stride, 1.0, 0.0, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               frame_k, d_err, nullptr, st, d_iters, false));
+      MK_HIP(mk_generic_iterate_mark(d_iters, d_err, B, it, max_iters, pos_tol, ori_tol, frame_k >= 0, st));
+      if (it == max_iters) break;
+      MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets,
+                             p->info.target_stride, dt, damping, B, nullptr, nullptr, nullptr, nullptr, d_v, d_status, -1,
+                             nullptr, nullptr, st, d_iters, true));
+      MK_HIP(mk_generic_integrate(p->model->dev, d_q, d_v, dt, B, st, d_iters));
+    }
+    MK_HIP(mk_generic_iterate_finish(d_iters, B, st));
+    return MK_OK;
+  }
   MK_HIP(mk_fused_launch_iterate(p->nc_kernel, p->d_fused, p->info.nq, d_q, d_targets, p->info.target_stride, dt,
                                  damping, B, max_iters, pos_tol, ori_tol, d_v, d_iters, d_err, d_status,
                                  static_cast<hipStream_t>(stream)));

@@ -995,7 +995,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MK_DENSE_WPE
                                                    double* __restrict__ c_out, double* __restrict__ G_out,
                                                    double* __restrict__ h_out, double* __restrict__ v_out,
                                                    int32_t* __restrict__ status_out, int eval_task,
-                                                   double* __restrict__ err_out, double* __restrict__ jac_out) {
+                                                   double* __restrict__ err_out, double* __restrict__ jac_out,
+                                                   const int32_t* __restrict__ skip_flags, int accumulate_status) {
   extern __shared__ double lds_base[];
   const int lane = threadIdx.x;
   const int n = m.nv, mrows = n_rows, mg = n_general;
@@ -1003,6 +1004,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MK_DENSE_WPE
   const int np = s.npad;
   const bool own = lane < n;
   for (long b = blockIdx.x; b < B; b += gridDim.x) {
+    // the iterated loop marks the problems that have left it: they are not touched again
+    if (skip_flags && (skip_flags[b] & MK_ITER_DONE_BIT)) continue;
     // ---- inputs, kinematics ----
     bool bad_lane = false;
     for (int i = lane; i < m.nq; i += 64) {
@@ -1316,7 +1319,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MK_DENSE_WPE
         x = 0.0;
       }
       if (own) v_out[b * n + lane] = x / dt;
-      if (lane == 0) status_out[b] = st;
+      if (lane == 0) status_out[b] = accumulate_status ? max(status_out[b], st) : st;
     }
     __syncthreads();
   }
@@ -1362,14 +1365,15 @@ static int dense_grid(int B, size_t lds) {
 hipError_t mk_dense_launch(const MkDevModel& m, const MkDenseProblem* d_problem, int n_rows, int n_general,
                            const double* q, const double* targets, int target_stride, double dt, double damping, int B,
                            double* P, double* c, double* G, double* h, double* v, int32_t* status, int eval_task,
-                           double* err, double* jac, hipStream_t s) {
+                           double* err, double* jac, hipStream_t s, const int32_t* skip_flags, bool accumulate_status) {
   const size_t lds = mk_dense_lds_bytes(m.nv, n_general, m.nq, target_stride, m.nbody, m.njnt, m.npath);
   if (lds == 0) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dense_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(dense_kernel, dim3(dense_grid(B, lds)), dim3(64), lds, s, m, d_problem, n_rows, n_general, m.npath, q,
-                     targets, target_stride, dt, damping, B, P, c, G, h, v, status, eval_task, err, jac);
+                     targets, target_stride, dt, damping, B, P, c, G, h, v, status, eval_task, err, jac, skip_flags,
+                     accumulate_status ? 1 : 0);
   return hipGetLastError();
 }
 

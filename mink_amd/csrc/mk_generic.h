@@ -77,7 +77,19 @@ struct MkDenseProblem {
   MkDenseLimit limit[MK_DENSE_MAX_LIMITS];
 };
 
-hipError_t mk_generic_integrate(const MkDevModel& m, double* q, const double* v, double dt, int B, hipStream_t s);
+// State bit of the iterated loop on the general path, kept in the problem's entry of the
+// `iters` array while the loop runs: the problem has left the loop.
+constexpr int32_t MK_ITER_DONE_BIT = 1 << 30;
+// (skip_flags: problems whose entry has MK_ITER_DONE_BIT set are left alone)
+hipError_t mk_generic_integrate(const MkDevModel& m, double* q, const double* v, double dt, int B, hipStream_t s,
+                                const int32_t* skip_flags = nullptr);
+// One step of the loop's bookkeeping: a live problem whose frame-task error meets the
+// thresholds (from the second pass on), or that has used up max_iters, gets the done bit;
+// any other live problem is about to be solved and its count becomes it + 1.
+hipError_t mk_generic_iterate_mark(int32_t* iters, const double* err, int B, int it, int max_iters, double pos_tol,
+                                   double ori_tol, bool has_frame, hipStream_t s);
+// Clears the done bits: `iters` then holds the solves executed.
+hipError_t mk_generic_iterate_finish(int32_t* iters, int B, hipStream_t s);
 // Pose (d_pose != null) and/or body-frame Jacobian (d_jac != null) of a frame given
 // by its body and local offset.
 hipError_t mk_generic_frame(const MkDevModel& m, const double* q, int B, int body, const double* lpos,
@@ -93,7 +105,8 @@ size_t mk_dense_lds_bytes(int nv, int n_general, int nq, int target_stride, int 
 hipError_t mk_dense_launch(const MkDevModel& m, const MkDenseProblem* d_problem, int n_rows, int n_general,
                            const double* q, const double* targets, int target_stride, double dt, double damping, int B,
                            double* P, double* c, double* G, double* h, double* v, int32_t* status, int eval_task,
-                           double* err, double* jac, hipStream_t s);
+                           double* err, double* jac, hipStream_t s, const int32_t* skip_flags = nullptr,
+                           bool accumulate_status = false);
 // Solves caller-provided dense QPs.
 hipError_t mk_dense_qp_launch(const double* P, const double* c, const double* G, const double* h, int n, int m, int B,
                               double* x, int32_t* status, hipStream_t s);

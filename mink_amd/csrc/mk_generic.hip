@@ -12,10 +12,11 @@ namespace {
 
 // q <- q (+) dt v, one thread per (problem, joint).
 __global__ void integrate_kernel(MkDevModel m, double* __restrict__ q, const double* __restrict__ v, double dt,
-                                 long total) {
+                                 long total, const int32_t* __restrict__ skip_flags) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const long b = idx / m.njnt;
+  if (skip_flags && (skip_flags[b] & MK_ITER_DONE_BIT)) return;
   const int j = (int)(idx - b * m.njnt);
   double* qq = q + b * m.nq + m.jnt_qposadr[j];
   const double* vv = v + b * m.nv + m.jnt_dofadr[j];
@@ -96,13 +97,46 @@ __global__ void check_limits_kernel(MkDevModel m, const double* __restrict__ q, 
   first[b] = bad;
 }
 
+__global__ void iterate_mark_kernel(int32_t* __restrict__ iters, const double* __restrict__ err, int B, int it,
+                                    int max_iters, double pos_tol, double ori_tol, int has_frame) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int32_t cur = iters[b];
+  if (cur & MK_ITER_DONE_BIT) return;
+  bool conv = false;
+  if (has_frame && it > 0) {
+    const double* e = err + (long)b * 6;
+    conv = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) <= pos_tol &&
+           sqrt(e[3] * e[3] + e[4] * e[4] + e[5] * e[5]) <= ori_tol;
+  }
+  iters[b] = (conv || it == max_iters) ? (cur | MK_ITER_DONE_BIT) : it + 1;
+}
+
+__global__ void iterate_finish_kernel(int32_t* __restrict__ iters, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) iters[b] &= ~MK_ITER_DONE_BIT;
+}
+
 }  // namespace
 
-hipError_t mk_generic_integrate(const MkDevModel& m, double* q, const double* v, double dt, int B, hipStream_t s) {
+hipError_t mk_generic_integrate(const MkDevModel& m, double* q, const double* v, double dt, int B, hipStream_t s,
+                                const int32_t* skip_flags) {
   const long total = (long)B * m.njnt;
   const int threads = 256;
   hipLaunchKernelGGL(integrate_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0, s, m, q, v,
-                     dt, total);
+                     dt, total, skip_flags);
+  return hipGetLastError();
+}
+
+hipError_t mk_generic_iterate_mark(int32_t* iters, const double* err, int B, int it, int max_iters, double pos_tol,
+                                   double ori_tol, bool has_frame, hipStream_t s) {
+  hipLaunchKernelGGL(iterate_mark_kernel, dim3((B + 255) / 256), dim3(256), 0, s, iters, err, B, it, max_iters, pos_tol,
+                     ori_tol, has_frame ? 1 : 0);
+  return hipGetLastError();
+}
+
+hipError_t mk_generic_iterate_finish(int32_t* iters, int B, hipStream_t s) {
+  hipLaunchKernelGGL(iterate_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, s, iters, B);
   return hipGetLastError();
 }
 

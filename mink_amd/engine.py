@@ -221,7 +221,7 @@ class DeviceProblem:
         if status is None:
             status = torch.empty((B,), dtype=torch.int32, device=self.device)
         v = out.get("v")
-        if v is None and want_v:
+        if v is None and (want_v or not self.fused):   # the general path keeps its state in v / iters / err
             v = torch.zeros((B, self.nv), dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
             L.check(self.lib.mk_solve_ik_iterate_batch(

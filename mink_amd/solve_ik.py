@@ -134,19 +134,14 @@ def solve_ik_iterate(configuration, tasks: Sequence[Task], dt: float, solver: st
     frame-task error), each configuration leaving the loop when its frame task error is
     below the thresholds.  Updates the configuration in place and returns
     ``dict(iters, err, status, v)``.  A problem the fused kernels serve (one FrameTask,
-    posture-like tasks, Configuration / Velocity limits) runs as one launch; any other task /
-    limit set runs the same loop as a sequence of launches of the general kernels, with the
-    exit test on its first FrameTask."""
+    posture-like tasks, Configuration / Velocity limits) runs as one launch; for any other task /
+    limit set the library issues the same loop as a sequence of launches of the general
+    kernels, with the exit test on the first FrameTask."""
     _check_solver(solver)
     if _has_custom(tasks, _resolve_limits(configuration, limits)):
         raise NotImplementedError("solve_ik_iterate runs built-in tasks and limits only; with user-defined Task / "
                                   "Limit subclasses call solve_ik and integrate_inplace step by step")
     prob, targets = get_problem(configuration, tasks, _resolve_limits(configuration, limits))
-    if not prob.fused:
-        res = _iterate_general(configuration, prob, targets, tasks, dt, damping, max_iters, pos_threshold,
-                               ori_threshold)
-        assert int((res["status"] != 0).sum()) == 0, "QP solver failed (infeasible limits or non-finite input)"
-        return {k: configuration._out(v) for k, v in res.items()}
     if not configuration.batched:
         res = prob.iterate_single_(configuration.q_tensor, targets, dt, damping, max_iters, pos_threshold,
                                    ori_threshold)
@@ -157,36 +152,3 @@ def solve_ik_iterate(configuration, tasks: Sequence[Task], dt: float, solver: st
     assert int((res["status"] != 0).sum()) == 0, "QP solver failed (infeasible limits or non-finite input)"
     return {k: configuration._out(v) for k, v in res.items()}
 
-
-def _iterate_general(configuration, prob, targets, tasks, dt, damping, max_iters, pos_threshold, ori_threshold):
-    """The callers' loop for problems outside the fused path: per iteration one error
-    evaluation, one solve and one integration launch over the whole batch; a configuration
-    that has met the thresholds (or used up max_iters) is left untouched from then on."""
-    from .tasks import FrameTask
-    q = configuration.q_tensor
-    B, dev = q.shape[0], q.device
-    k = next((i for i, t in enumerate(tasks) if type(t) is FrameTask), None)
-    done = torch.zeros(B, dtype=torch.bool, device=dev)
-    iters = torch.zeros(B, dtype=torch.int32, device=dev)
-    status = torch.zeros(B, dtype=torch.int32, device=dev)
-    err = torch.zeros((B, 6), dtype=torch.float64, device=dev)
-    v_last = torch.zeros((B, prob.nv), dtype=torch.float64, device=dev)
-    for it in range(max_iters + 1):
-        if k is not None:
-            e = prob.task_eval(k, 6, q, targets)[0]
-            err = torch.where(done[:, None], err, e)
-            conv = (e[:, :3].norm(dim=1) <= pos_threshold) & (e[:, 3:].norm(dim=1) <= ori_threshold)
-            if it > 0:
-                done = done | conv
-        if it == max_iters or bool(done.all()):
-            break
-        live = ~done
-        v, st = prob.solve(q, targets, dt, damping)
-        v = torch.where(live[:, None], v, torch.zeros_like(v))
-        status = torch.maximum(status, torch.where(live, st, torch.zeros_like(st)))
-        iters = torch.where(live, torch.full_like(iters, it + 1), iters)
-        v_last = torch.where(live[:, None], v, v_last)
-        q_next = q.clone()
-        configuration.dmodel.integrate_(q_next, v, dt)
-        q.copy_(torch.where(live[:, None], q_next, q))
-    return dict(iters=iters, err=err, status=status, v=v_last)

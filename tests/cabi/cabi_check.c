@@ -140,6 +140,50 @@ int main(void) {
   }
   if (closer < B * 9 / 10) { printf("only %d of %d problems approached their target\n", closer, B); return 6; }
 
+  /* 2b. the same loop for a task set outside the fused path (an extra relative-frame task):
+   *     issued as launches of the general kernels, state in d_v / d_iters / d_err */
+  {
+    const double rel_cost[6] = {0.1, 0.1, 0.1, 0.1, 0.1, 0.1};
+    mk_task_desc t3[3];
+    memcpy(t3, tasks, sizeof(tasks));
+    memset(&t3[2], 0, sizeof(t3[2]));
+    t3[2].type = MK_TASK_RELATIVE_FRAME; t3[2].frame_type = MK_FRAME_SITE; t3[2].frame_id = 0;
+    t3[2].root_type = MK_FRAME_BODY; t3[2].root_id = 2; t3[2].ncost = 6; t3[2].gain = 1.0; t3[2].cost = rel_cost;
+    mk_problem* gen = NULL;
+    CHECK_MK(mk_problem_create(model, t3, 3, limits, 2, &gen));
+    mk_problem_info gi;
+    CHECK_MK(mk_problem_get_info(gen, &gi));
+    if (gi.fused || gi.target_stride != 14) { printf("unexpected general problem: fused %d stride %d\n", gi.fused, gi.target_stride); return 8; }
+    static double tg2[B * 14];
+    CHECK_HIP(hipMemcpy(tg, d_tg, sizeof(tg), hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b) {
+      memcpy(tg2 + 14 * b, tg + 7 * b, 7 * sizeof(double));
+      const double rel_target[7] = {1, 0, 0, 0, 0.3, 0.0, 0.2};
+      memcpy(tg2 + 14 * b + 7, rel_target, sizeof(rel_target));
+    }
+    double* d_tg2 = to_device(tg2, sizeof(tg2));
+    CHECK_HIP(hipMemcpy(d_q, q, sizeof(q), hipMemcpyHostToDevice));
+    if (mk_solve_ik_iterate_batch(gen, d_q, d_tg2, dt, damping, B, 5, 1e-4, 1e-4, NULL, d_it, d_err, d_st, stream) != MK_ERR_INVALID) {
+      printf("the general loop accepted a missing state array\n");
+      return 8;
+    }
+    CHECK_MK(mk_solve_ik_iterate_batch(gen, d_q, d_tg2, dt, damping, B, 5, -1.0, -1.0, d_v, d_it, d_err, d_st, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+    CHECK_HIP(hipMemcpy(err1, d_err, sizeof(err1), hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(iters, d_it, sizeof(iters), hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(st, d_st, sizeof(st), hipMemcpyDeviceToHost));
+    int closer2 = 0;
+    for (int b = 0; b < B; ++b) {
+      double n0 = 0, n1 = 0;
+      for (int k = 0; k < 6; ++k) { n0 += err0[b * 6 + k] * err0[b * 6 + k]; n1 += err1[b * 6 + k] * err1[b * 6 + k]; }
+      closer2 += n1 < n0;
+      if (iters[b] != 5 || st[b] != 0) { printf("general loop, problem %d: %d iterations, status %d\n", b, iters[b], st[b]); return 8; }
+    }
+    if (closer2 < B * 8 / 10) { printf("general loop: only %d of %d problems approached their target\n", closer2, B); return 8; }
+    mk_problem_destroy(gen);
+    (void)hipFree(d_tg2);
+  }
+
   /* 3. errors are reported, not thrown */
   if (mk_solve_ik_batch(prob, d_q, NULL, dt, damping, B, d_v, d_st, stream) != MK_ERR_INVALID || strlen(mk_last_error()) == 0) {
     printf("missing targets were not rejected\n");
