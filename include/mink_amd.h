@@ -218,7 +218,8 @@ int mk_task_eval_batch(const mk_problem* problem, int32_t task, const double* d_
 
 /* qpsolvers.solve_problem(Problem(P, q, G, h), solver) (mink/solve_ik.py:101):
  * min 1/2 x'Px + c'x s.t. Gx <= h for B independent dense problems, P positive
- * definite; n <= 64 and (4 n^2 + m n) * 8 bytes within the LDS budget (~150 KB).  d_x [B, n]. */
+ * definite; n <= 64 and (4 n^2 + m n) * 8 bytes within the LDS budget (~150 KB).  d_x [B, n].
+ * A P that is not positive definite or any non-finite entry gives status 3 and x = 0. */
 int mk_qp_solve_batch(const double* d_P, const double* d_c, const double* d_G, const double* d_h,
                       int32_t n, int32_t m, int32_t B, double* d_x, int32_t* d_status,
                       void* stream);

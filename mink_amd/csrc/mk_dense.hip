@@ -1339,8 +1339,14 @@ __global__ __launch_bounds__(64) void dense_qp_kernel(const double* __restrict__
     for (int idx = lane; idx < mrows * n; idx += 64) s.Gg[(idx / n) * np + idx % n] = G[b * mrows * n + idx];
     for (int idx = lane; idx < mrows; idx += 64) s.hg[idx] = h[b * mrows + idx];
     __syncthreads();
-    double x;
-    const int st = gi_solve(s, n, mrows, lane, -INFINITY, INFINITY, x);
+    double x = 0.0;
+    int st = gi_solve(s, n, mrows, lane, -INFINITY, INFINITY, x);
+    // a factorisation that fails (P not positive definite, non-finite input) or a
+    // non-finite solution: status 3 and x = 0
+    if (st == 3 || __ballot(lane < n && !(fabs(x) < INFINITY)) != 0ull) {
+      st = 3;
+      x = 0.0;
+    }
     if (lane < n) x_out[b * n + lane] = x;
     if (lane == 0) status_out[b] = st;
     __syncthreads();

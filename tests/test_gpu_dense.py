@@ -84,6 +84,7 @@ def test_dense_qp_random_general_rows(env):
     h = rng.uniform(0.05, 1.0, size=(B, m))
     x, st = qp_solve(dev(P), dev(c), dev(G), dev(h))
     x = x.cpu().numpy()
+    x_all = x
     assert int(st.abs().sum()) == 0
     nact = 0
     for b in range(B):
@@ -97,6 +98,14 @@ def test_dense_qp_random_general_rows(env):
     Gi = np.zeros((1, 2, n)); Gi[0, 0, 0] = 1; Gi[0, 1, 0] = -1
     x, st = qp_solve(dev(P[:1]), dev(c[:1]), dev(Gi), dev(np.array([[-1.0, -1.0]])))
     assert st.cpu().tolist() == [2]
+    # not positive definite / non-finite: status 3, x = 0, neighbours untouched
+    Pb, cb = P[:3].copy(), c[:3].copy()
+    Pb[0] = -np.eye(n)
+    cb[2, 1] = np.nan
+    xb, st = qp_solve(dev(Pb), dev(cb), dev(G[:3]), dev(h[:3]))
+    assert st.cpu().tolist() == [3, 0, 3]
+    assert float(xb[0].abs().max()) == 0.0 and float(xb[2].abs().max()) == 0.0
+    np.testing.assert_array_equal(xb[1].cpu().numpy(), x_all[1])
 
 
 def test_relative_frame_com_and_collision(env, golden_dir):
