@@ -73,6 +73,37 @@ class ConfigurationLimit(Limit):
         self.model = model
         self.gain = gain
         self.min_distance_from_limits = min_distance_from_limits
+        # the kernels derive the bounds from the model's joint ranges; a caller that
+        # overwrites lower / upper afterwards (the reference reads them at every call,
+        # mink/limits/configuration_limit.py:69-124) is served by the generic route instead
+        self._built_bounds = (lower.copy(), upper.copy())
+        self._index_qadr = np.array([q for j in range(model.njnt)
+                                     if int(model.jnt_type[j]) != JNT_FREE and model.jnt_limited[j]
+                                     for q in range(model.jnt_qposadr[j], model.jnt_qposadr[j] + dof_width(int(model.jnt_type[j])))],
+                                    dtype=np.int64)
+
+    def _overridden(self) -> bool:
+        return not (np.array_equal(self.lower, self._built_bounds[0]) and np.array_equal(self.upper, self._built_bounds[1]))
+
+    def _is_custom(self) -> bool:
+        return self._overridden()
+
+    def compute_qp_inequalities(self, configuration, dt: float) -> Constraint:
+        if not self._overridden():
+            return super().compute_qp_inequalities(configuration, dt)
+        if self.projection_matrix is None:
+            return Constraint()
+        import torch
+        if any(int(t) == 1 for t in self.model.jnt_type[self.model.jnt_limited != 0]):
+            raise LimitDefinitionError("overridden bounds are supported for hinge and slide joints only")
+        q = configuration.q_tensor[:, self._index_qadr]
+        lo = torch.as_tensor(np.asarray(self.lower)[self._index_qadr], dtype=torch.float64).to(q.device)
+        hi = torch.as_tensor(np.asarray(self.upper)[self._index_qadr], dtype=torch.float64).to(q.device)
+        P = torch.as_tensor(self.projection_matrix, dtype=torch.float64).to(q.device)
+        B = q.shape[0]
+        G = torch.cat([P, -P], dim=0)[None].expand(B, -1, -1).contiguous()
+        h = torch.cat([self.gain * (hi[None] - q), self.gain * (q - lo[None])], dim=1)
+        return Constraint(G=configuration._out(G), h=configuration._out(h))
 
     def _key(self, model):
         if self.projection_matrix is None:

@@ -220,3 +220,26 @@ def test_configuration_and_velocity_limit_cases(model, fmodel, cfg):
     np.testing.assert_allclose(h, 1e-2 * np.array([1.0, 2.0, 3.0, 0.5] * 2), atol=1e-15)
     # a model without limited joints / without velocity limits gives an inactive constraint
     assert mink.VelocityLimit(model).compute_qp_inequalities(cfg, 1e-3).inactive
+
+
+def test_configuration_limit_repulsion(model, cfg):
+    """tests/test_configuration_limit.py:147-160 of the reference: with the bounds overwritten
+    to q -/+ slack the rows allow at most the slack, and solve_ik honours them."""
+    dt, slack_vel = 1e-3, 5e-4
+    limit = mink.ConfigurationLimit(model, gain=0.5)
+    limit.lower = cfg.integrate(-slack_vel * np.ones(cfg.nv), dt)
+    limit.upper = cfg.integrate(+slack_vel * np.ones(cfg.nv), dt)
+    G, h = limit.compute_qp_inequalities(cfg, dt)
+    assert np.max(h) < slack_vel * dt + 1e-10 and np.min(h) > -slack_vel * dt - 1e-10
+    assert G.shape == (2 * len(limit.indices), model.nv)
+    # a task that pulls hard on joint_2 moves it by no more than gain * slack per step
+    posture = mink.PostureTask(model, cost=1.0)
+    target = cfg.q.copy()
+    j2 = int(model.jnt_qposadr[model.joint_id("joint_2")])
+    target[j2] += 1.0
+    posture.set_target(target)
+    v = mink.solve_ik(cfg, [posture], dt, "quadprog", 1e-6, limits=[limit])
+    d2 = int(model.jnt_dofadr[model.joint_id("joint_2")])
+    assert abs(v[d2] * dt - 0.5 * slack_vel * dt) < 1e-12
+    d1 = int(model.jnt_dofadr[model.joint_id("joint_1")])      # an unlimited joint is free to move
+    assert abs(v[d1]) < 1e-9 and abs(v[d2]) > 0
