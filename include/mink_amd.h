@@ -224,6 +224,57 @@ int mk_qp_solve_batch(const double* d_P, const double* d_c, const double* d_G, c
                       int32_t n, int32_t m, int32_t B, double* d_x, int32_t* d_status,
                       void* stream);
 
+/* Operations of mink.lie (mink/lie/so3.py, mink/lie/se3.py, mink/lie/base.py).  Operand
+ * widths in doubles, (a, b) -> out: rotations are 4 (wxyz), poses 7 (wxyz_xyz), tangents
+ * 3 / 6 (v; omega), matrices row-major. */
+enum {
+  MK_SO3_EXP = 0,          /* so3.py:158-173   (3)    -> 4  */
+  MK_SO3_LOG = 1,          /* so3.py:176-191   (4)    -> 3  */
+  MK_SO3_MULTIPLY = 2,     /* so3.py:148-151   (4, 4) -> 4  */
+  MK_SO3_INVERSE = 3,      /* so3.py:136-137   (4)    -> 4  */
+  MK_SO3_NORMALIZE = 4,    /* so3.py:139-140   (4)    -> 4  */
+  MK_SO3_APPLY = 5,        /* so3.py:143-146   (4, 3) -> 3  */
+  MK_SO3_AS_MATRIX = 6,    /* so3.py:111-114, adjoint so3.py:194   (4) -> 9 */
+  MK_SO3_FROM_MATRIX = 7,  /* so3.py:79-84 (mju_mat2Quat)          (9) -> 4 */
+  MK_SO3_LJAC = 8,         /* so3.py:200-212   (3)    -> 9  */
+  MK_SO3_LJACINV = 9,      /* so3.py:214-226   (3)    -> 9  */
+  MK_SO3_RJAC = 10,        /* base.py:147      (3)    -> 9  */
+  MK_SO3_RJACINV = 11,     /* base.py:151      (3)    -> 9  */
+  MK_SO3_JLOG = 12,        /* base.py:155      (4)    -> 9  */
+  MK_SO3_RPLUS = 13,       /* base.py:109      (4, 3) -> 4  */
+  MK_SO3_LPLUS = 14,       /* base.py:117      (4, 3) -> 4  */
+  MK_SO3_RMINUS = 15,      /* base.py:113  a (-) b = log(b^-1 a)   (4, 4) -> 3 */
+  MK_SO3_LMINUS = 16,      /* base.py:121  log(a b^-1)             (4, 4) -> 3 */
+  MK_SO3_AS_RPY = 17,      /* so3.py:116-133   (4)    -> 3 (roll, pitch, yaw) */
+  MK_SO3_FROM_RPY = 18,    /* so3.py:66-77     (3)    -> 4  */
+  MK_SE3_EXP = 32,         /* se3.py:112-134   (6)    -> 7  */
+  MK_SE3_LOG = 33,         /* se3.py:159-185   (7)    -> 6  */
+  MK_SE3_MULTIPLY = 34,    /* se3.py:153-157   (7, 7) -> 7  */
+  MK_SE3_INVERSE = 35,     /* se3.py:136-141   (7)    -> 7  */
+  MK_SE3_NORMALIZE = 36,   /* se3.py:143-147   (7)    -> 7  */
+  MK_SE3_APPLY = 37,       /* se3.py:149-151   (7, 3) -> 3  */
+  MK_SE3_AS_MATRIX = 38,   /* se3.py:106-110   (7)    -> 16 */
+  MK_SE3_FROM_MATRIX = 39, /* se3.py:68-75     (16)   -> 7  */
+  MK_SE3_ADJOINT = 40,     /* se3.py:187-194   (7)    -> 36 */
+  MK_SE3_LJAC = 41,        /* se3.py:199-207   (6)    -> 36 */
+  MK_SE3_LJACINV = 42,     /* se3.py:210-218   (6)    -> 36 */
+  MK_SE3_RJAC = 43,        /* base.py:147      (6)    -> 36 */
+  MK_SE3_RJACINV = 44,     /* base.py:151      (6)    -> 36 */
+  MK_SE3_JLOG = 45,        /* base.py:155      (7)    -> 36 */
+  MK_SE3_RPLUS = 46,       /* base.py:109      (7, 6) -> 7  */
+  MK_SE3_LPLUS = 47,       /* base.py:117      (7, 6) -> 7  */
+  MK_SE3_RMINUS = 48,      /* base.py:113      (7, 7) -> 6  */
+  MK_SE3_LMINUS = 49       /* base.py:121      (7, 7) -> 6  */
+};
+
+/* One operation of mink.lie on B independent elements: d_a [B, wa], d_b [B, wb] (NULL for
+ * unary operations), d_out [B, wo].  The device functions are the ones the IK kernels use
+ * for their frame tasks. */
+int mk_lie_batch(int32_t op, const double* d_a, const double* d_b, int32_t B, double* d_out,
+                 void* stream);
+/* Operand widths of an operation; returns MK_ERR_INVALID for an unknown op. */
+int mk_lie_op_shape(int32_t op, int32_t* wa, int32_t* wb, int32_t* wo);
+
 /* Message of the last error on the calling thread ("" if none). */
 const char* mk_last_error(void);
 

@@ -174,9 +174,22 @@ _SIGNATURES = {
                                      C.c_void_p]),
     "mk_qp_solve_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mk_lie_batch": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mk_lie_op_shape": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+# operations of mk_lie_batch (include/mink_amd.h)
+LIE_OPS = {
+    "so3_exp": 0, "so3_log": 1, "so3_multiply": 2, "so3_inverse": 3, "so3_normalize": 4, "so3_apply": 5,
+    "so3_as_matrix": 6, "so3_from_matrix": 7, "so3_ljac": 8, "so3_ljacinv": 9, "so3_rjac": 10, "so3_rjacinv": 11,
+    "so3_jlog": 12, "so3_rplus": 13, "so3_lplus": 14, "so3_rminus": 15, "so3_lminus": 16, "so3_as_rpy": 17,
+    "so3_from_rpy": 18,
+    "se3_exp": 32, "se3_log": 33, "se3_multiply": 34, "se3_inverse": 35, "se3_normalize": 36, "se3_apply": 37,
+    "se3_as_matrix": 38, "se3_from_matrix": 39, "se3_adjoint": 40, "se3_ljac": 41, "se3_ljacinv": 42, "se3_rjac": 43,
+    "se3_rjacinv": 44, "se3_jlog": 45, "se3_rplus": 46, "se3_lplus": 47, "se3_rminus": 48, "se3_lminus": 49,
+}
 
 _lib = None
 

@@ -135,6 +135,38 @@ class Configuration:
         b = int(bad[0, 0])
         self._report_limit_violation(b, int(first[b]), bad.shape[0], safety_break)
 
+    # ---- deferred reports of the batched, asynchronous calls ---------------------
+    def _defer_limit_check(self, tol: float = 1e-6) -> None:
+        """Queue the limit check on the stream and keep its result on the device; nothing
+        waits for it.  `check()` turns the latest one into the reference's warning."""
+        self._pending_first = self.dmodel.first_limit_violation(self._q, tol)
+
+    def _defer_status(self, status: torch.Tensor) -> None:
+        """Fold the solver status of a batched call into a running per-problem maximum on
+        the device (one small element-wise kernel, no synchronisation)."""
+        acc = getattr(self, "_pending_status", None)
+        self._pending_status = status.clone() if acc is None or acc.shape != status.shape \
+            else torch.maximum(acc, status)
+
+    def check(self) -> None:
+        """Wait for the batched calls issued so far and report what they deferred: a warning
+        for the limit check of the last `solve_ik(..., safety_break=False)` (the reference's
+        logging.warning, mink/configuration.py:107-110) and an AssertionError if any QP since
+        the last `check()` failed (the reference's assert, mink/solve_ik.py:103)."""
+        first = getattr(self, "_pending_first", None)
+        self._pending_first = None
+        if first is not None and first.shape[0] == self.batch_size:
+            bad = torch.nonzero(first >= 0)
+            if bad.numel():
+                b = int(bad[0, 0])
+                self._report_limit_violation(b, int(first[b]), bad.shape[0], False)
+        status = getattr(self, "_pending_status", None)
+        self._pending_status = None
+        if status is not None:
+            n_bad = int((status != 0).sum())
+            assert n_bad == 0, (f"QP solver failed for {n_bad} of {status.shape[0]} problems (infeasible limits or "
+                                f"non-finite input); worst status {int(status.max())}")
+
     def _report_limit_violation(self, b: int, jnt: int, n_bad: int, safety_break: bool) -> None:
         qval = float(self._q[b, self.model.jnt_qposadr[jnt]])
         qmin, qmax = (float(x) for x in self.model.jnt_range[jnt])

@@ -29,6 +29,10 @@ hipError_t mk_fused_launch_move_to(int nc, const MkFusedDesc* d_desc, int nq, do
                                    int32_t* steps, int32_t* reached, int32_t* solves, int32_t* status,
                                    hipStream_t stream);
 
+// ---- implemented in mk_lie.hip ----
+int mk_lie_shape(int op, int* wa, int* wb, int* wo);
+hipError_t mk_lie_launch(int op, const double* a, const double* b, int B, double* out, hipStream_t s);
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -944,6 +948,22 @@ int mk_qp_solve_batch(const double* d_P, const double* d_c, const double* d_G, c
   if (!d_P || !d_c || !d_x || !d_status || (m > 0 && (!d_G || !d_h))) return fail(MK_ERR_INVALID, "null argument");
   if (mk_dense_lds_bytes(n, m, 0, 0, 0, 0, 0) == 0) return fail(MK_ERR_UNSUPPORTED, "QP too large for the LDS-resident solver (n <= 64 and about (4 n^2 + m n) * 8 bytes <= 150 KB)");
   MK_HIP(mk_dense_qp_launch(d_P, d_c, d_G, d_h, n, m, B, d_x, d_status, static_cast<hipStream_t>(stream)));
+  return MK_OK;
+}
+
+int mk_lie_op_shape(int32_t op, int32_t* wa, int32_t* wb, int32_t* wo) {
+  if (!wa || !wb || !wo) return fail(MK_ERR_INVALID, "null argument");
+  if (!mk_lie_shape(op, wa, wb, wo)) return fail(MK_ERR_INVALID, "unknown Lie operation %d", op);
+  return MK_OK;
+}
+
+int mk_lie_batch(int32_t op, const double* d_a, const double* d_b, int32_t B, double* d_out, void* stream) {
+  int wa, wb, wo;
+  if (!mk_lie_shape(op, &wa, &wb, &wo)) return fail(MK_ERR_INVALID, "unknown Lie operation %d", op);
+  if (B < 0) return fail(MK_ERR_INVALID, "negative batch");
+  if (B == 0) return MK_OK;
+  if (!d_a || !d_out || (wb > 0 && !d_b)) return fail(MK_ERR_INVALID, "null argument");
+  MK_HIP(mk_lie_launch(op, d_a, wb > 0 ? d_b : nullptr, B, d_out, static_cast<hipStream_t>(stream)));
   return MK_OK;
 }
 

@@ -1374,9 +1374,8 @@ hipError_t mk_dense_launch(const MkDevModel& m, const MkDenseProblem* d_problem,
                            double* err, double* jac, hipStream_t s, const int32_t* skip_flags, bool accumulate_status) {
   const size_t lds = mk_dense_lds_bytes(m.nv, n_general, m.nq, target_stride, m.nbody, m.njnt, m.npath);
   if (lds == 0) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dense_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  static MkLdsGrant grant;
+  if (hipError_t e = mk_grant_lds(reinterpret_cast<const void*>(dense_kernel), lds, grant); e != hipSuccess) return e;
   hipLaunchKernelGGL(dense_kernel, dim3(dense_grid(B, lds)), dim3(64), lds, s, m, d_problem, n_rows, n_general, m.npath, q,
                      targets, target_stride, dt, damping, B, P, c, G, h, v, status, eval_task, err, jac, skip_flags,
                      accumulate_status ? 1 : 0);
@@ -1387,9 +1386,8 @@ hipError_t mk_dense_qp_launch(const double* P, const double* c, const double* G,
                               double* x, int32_t* status, hipStream_t s) {
   const size_t lds = mk_dense_lds_bytes(n, m, 0, 0, 0, 0, 0);
   if (lds == 0) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dense_qp_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  static MkLdsGrant grant;
+  if (hipError_t e = mk_grant_lds(reinterpret_cast<const void*>(dense_qp_kernel), lds, grant); e != hipSuccess) return e;
   hipLaunchKernelGGL(dense_qp_kernel, dim3(dense_grid(B, lds)), dim3(64), lds, s, P, c, G, h, n, m, B, x, status);
   return hipGetLastError();
 }

@@ -332,9 +332,8 @@ MK_DEV Twist se3_log(Q4 q, V3 t) {
   return Twist{mul(Vinv, t), w};
 }
 
-// Blocks of SE3.ljacinv(xi) = [[Ji, B], [0, Ji]] with B = -Ji Q Ji
-// (mink/lie/se3.py:210-249, mink/lie/so3.py:214-226); Ji = I, B = 0 when the reference
-// returns exactly I6 (theta^2 below the switch).
+// The Q block of the SE3 Jacobians (mink/lie/se3.py:222-249) for theta^2 = |w|^2 above the
+// small-angle switch, given rth = 1/theta, th = theta, s = sin(theta), c = cos(theta).
 //
 // Q is the reference's sum of products of the skew matrices V = [v]x, W = [w]x,
 //   Q = V/2 + b (WV + VW + WVW) - c (VWW - (VWW)' - 3 WVW) + d (WVWW + WWVW),
@@ -342,20 +341,8 @@ MK_DEV Twist se3_log(Q4 q, V3 t) {
 //   WV + VW = v w' + w v' - 2 s I,   WVW = -s W,   VWW - (VWW)' = [n x w]x - 2 s W,
 //   WVWW + WWVW = -2 s (w w' - |w|^2 I),
 // i.e. a skew part [v/2 - (b + c) s w - c (n x w)]x plus a symmetric part.
-MK_DEV void se3_ljacinv_blocks(Twist xi, M3& Ji, M3& B) {
-  const double t2 = dot(xi.w, xi.w);
-  if (t2 < MK_LIE_EPS) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { Ji.m[i] = (i % 4 == 0) ? 1.0 : 0.0; B.m[i] = 0.0; }
-    return;
-  }
-  const double rth = mk_rsqrt(t2), th = t2 * rth;
-  double s, c;
-  mk_sincos(th, &s, &c);
-  // SO3.ljacinv switches on theta (not theta^2); theta >= 1e-5 here, so closed form.
+MK_DEV M3 se3_Q_closed(Twist xi, double t2, double rth, double th, double s, double c) {
   const double it2 = rth * rth;
-  const double A = it2 * (1.0 - (th * s * mk_rcp(2.0 * (1.0 - c))));
-  Ji = rodrigues_like(xi.w, -0.5, A);
   const double ith = rth;
   const double Bc = (th - s) * it2 * ith;
   const double Cc = (1.0 - 0.5 * t2 - c) * it2 * it2;
@@ -376,6 +363,27 @@ MK_DEV void se3_ljacinv_blocks(Twist xi, M3& Ji, M3& B) {
   Q.m[1] = sxy - k.z; Q.m[3] = sxy + k.z;
   Q.m[2] = sxz + k.y; Q.m[6] = sxz - k.y;
   Q.m[5] = syz - k.x; Q.m[7] = syz + k.x;
+  return Q;
+}
+
+// Blocks of SE3.ljacinv(xi) = [[Ji, B], [0, Ji]] with B = -Ji Q Ji
+// (mink/lie/se3.py:210-249, mink/lie/so3.py:214-226); Ji = I, B = 0 when the reference
+// returns exactly I6 (theta^2 below the switch).
+MK_DEV void se3_ljacinv_blocks(Twist xi, M3& Ji, M3& B) {
+  const double t2 = dot(xi.w, xi.w);
+  if (t2 < MK_LIE_EPS) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { Ji.m[i] = (i % 4 == 0) ? 1.0 : 0.0; B.m[i] = 0.0; }
+    return;
+  }
+  const double rth = mk_rsqrt(t2), th = t2 * rth;
+  double s, c;
+  mk_sincos(th, &s, &c);
+  // SO3.ljacinv switches on theta (not theta^2); theta >= 1e-5 here, so closed form.
+  const double it2 = rth * rth;
+  const double A = it2 * (1.0 - (th * s * mk_rcp(2.0 * (1.0 - c))));
+  Ji = rodrigues_like(xi.w, -0.5, A);
+  const M3 Q = se3_Q_closed(xi, t2, rth, th, s, c);
   M3 JQ = mmul(Ji, Q);
   B = mmul(JQ, Ji);
 #pragma unroll

@@ -17,6 +17,7 @@
 // with the active bounds expressed as lane masks, so 64 problems with different
 // active sets run one instruction stream.
 #include "mk_device.h"
+#include "mk_generic.h"
 
 // One wave per workgroup; register budget / occupancy target of the fused kernels.
 #ifndef MK_KERNEL_ATTR
@@ -814,14 +815,12 @@ __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restric
 }  // namespace
 
 // Host-side launchers (called from mk_api.hip).
-// Dynamic LDS beyond the 64 KB default needs the kernel's limit raised (long q rows with a
-// 12-dof chain); the CU has 160 KB.
-template <class K>
-static hipError_t allow_lds(K kernel, size_t lds) {
-  if (lds <= 64 * 1024) return hipSuccess;
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)lds);
+// Dynamic LDS beyond the 64 KB default (long q rows with a 12-dof chain) needs the kernel's
+// limit raised, once per kernel instantiation and device; the CU has 160 KB.
+template <auto Kernel>
+static hipError_t allow_lds(size_t lds) {
+  static MkLdsGrant grant;   // one per instantiation of this template, i.e. per kernel
+  return mk_grant_lds(reinterpret_cast<const void*>(Kernel), lds, grant);
 }
 
 template <int NC>
@@ -830,7 +829,7 @@ static hipError_t launch_step(const MkFusedDesc* d_desc, int nq, const double* q
                               hipStream_t stream) {
   const int blocks = (B + 63) / 64;
   const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
-  if (hipError_t e = allow_lds(fused_step_kernel<NC>, lds); e != hipSuccess) return e;
+  if (hipError_t e = allow_lds<fused_step_kernel<NC>>(lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(fused_step_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, targets, target_stride,
                      dt, damping, B, v, status);
   return hipGetLastError();
@@ -843,7 +842,7 @@ static hipError_t launch_iterate(const MkFusedDesc* d_desc, int nq, double* q, c
                                  hipStream_t stream) {
   const int blocks = (B + 63) / 64;
   const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
-  if (hipError_t e = allow_lds(fused_iterate_kernel<NC>, lds); e != hipSuccess) return e;
+  if (hipError_t e = allow_lds<fused_iterate_kernel<NC>>(lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(fused_iterate_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
                      target_stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status);
   return hipGetLastError();
@@ -883,7 +882,7 @@ static hipError_t launch_move_to(const MkFusedDesc* d_desc, int nq, double* q, c
                                  int32_t* reached, int32_t* solves, int32_t* status, hipStream_t stream) {
   const int blocks = (B + 63) / 64;
   const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
-  if (hipError_t e = allow_lds(fused_move_to_kernel<NC>, lds); e != hipSuccess) return e;
+  if (hipError_t e = allow_lds<fused_move_to_kernel<NC>>(lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(fused_move_to_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, goals, dt, damping, B,
                      max_steps, max_iters, pos_tol, ori_tol, wp_pos_thr, wp_pos_step, wp_rot_thr, steps, reached,
                      solves, status);

@@ -5,6 +5,30 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
+// Dynamic LDS beyond the 64 KB default needs the kernel's limit raised.  The largest size
+// already granted is remembered per kernel and device, so this is one runtime call per kernel
+// and device (or per new high-water mark), not one per launch.
+struct MkLdsGrant {
+  std::atomic<size_t> granted[32];
+};
+inline hipError_t mk_grant_lds(const void* kernel, size_t lds, MkLdsGrant& g) {
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  int dev = -1;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  const bool tracked = dev >= 0 && dev < 32;
+  const size_t have = tracked ? g.granted[dev].load(std::memory_order_relaxed) : 0;
+  if (lds <= (have > 64 * 1024 ? have : 64 * 1024)) return hipSuccess;
+  if (hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
+    return e;
+  if (tracked) {
+    size_t cur = have;
+    while (cur < lds && !g.granted[dev].compare_exchange_weak(cur, lds, std::memory_order_relaxed)) {}
+  }
+  return hipSuccess;
+}
+
 struct MkDevModel {
   int32_t nq, nv, nbody, njnt, ngeom;
   int32_t npath;   // entries of path_data

@@ -2,10 +2,12 @@
 
 Same interface as the reference's ``mink.lie`` (mink/lie/base.py, so3.py, se3.py) --
 quaternions are (w, x, y, z), SE3 parameters (qw, qx, qy, qz, x, y, z), tangents
-(v; omega), Taylor switches at 1e-10 -- with an arbitrary leading batch shape, on
-torch tensors (CPU or GPU).  These classes build and post-process *targets*; the Lie
-arithmetic of the IK path itself (log / jlog inside the frame tasks) runs in the HIP
-kernels.
+(v; omega), Taylor switches at 1e-10 -- with an arbitrary leading batch shape.
+
+Elements held in GPU tensors are operated on by the HIP kernels (``mk_lie_batch``, one
+element per lane, the same device functions the IK kernels use for their frame tasks).
+Elements held in host tensors (single targets, fixtures, configuration-free code) are
+evaluated by the torch expressions below; nothing on the IK path goes through those.
 """
 from __future__ import annotations
 
@@ -51,6 +53,41 @@ def _qmul(a, b):
                         aw * bz + ax * by - ay * bx + az * bw], -1)
 
 
+_MAT_SHAPE = {9: (3, 3), 16: (4, 4), 36: (6, 6)}
+
+
+def _on_gpu(*ts) -> bool:
+    return any(isinstance(t, torch.Tensor) and t.is_cuda for t in ts)
+
+
+def _hip(op: str, a: torch.Tensor, b: torch.Tensor = None) -> torch.Tensor:
+    """One mk_lie_batch call over the broadcast batch shape of a (and b)."""
+    import ctypes as C
+
+    from . import _lib as L
+    lib = L.load_library()
+    code = L.LIE_OPS[op]
+    wa, wb, wo = C.c_int32(), C.c_int32(), C.c_int32()
+    L.check(lib.mk_lie_op_shape(code, C.byref(wa), C.byref(wb), C.byref(wo)))
+    wa, wb, wo = wa.value, wb.value, wo.value
+    dev = a.device if a.is_cuda else b.device
+    a = a.to(device=dev, dtype=torch.float64)
+    if wa in _MAT_SHAPE:
+        a = a.reshape(*a.shape[:-2], wa)
+    batch = a.shape[:-1]
+    if wb:
+        b = b.to(device=dev, dtype=torch.float64)
+        batch = torch.broadcast_shapes(batch, b.shape[:-1])
+        b = b.expand(*batch, wb).reshape(-1, wb).contiguous()
+    a = a.expand(*batch, wa).reshape(-1, wa).contiguous()
+    n = a.shape[0]
+    out = torch.empty((n, wo), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        L.check(lib.mk_lie_batch(code, a.data_ptr(), b.data_ptr() if wb else None, n, out.data_ptr(),
+                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return out.reshape(*batch, *_MAT_SHAPE.get(wo, (wo,)))
+
+
 def _eye(n, like):
     return torch.eye(n, dtype=torch.float64, device=like.device).expand(*like.shape[:-1], n, n)
 
@@ -64,34 +101,59 @@ class MatrixLieGroup:
         return self.multiply(other)
 
     def rplus(self, other):
+        p = self.parameters()
+        if _on_gpu(p):
+            return type(self)(_hip(self._prefix + "rplus", p, _t(other, p)))
         return self @ type(self).exp(other)
 
     def rminus(self, other):
+        p = self.parameters()
+        if _on_gpu(p, other.parameters()):
+            return _hip(self._prefix + "rminus", p, other.parameters())
         return (other.inverse() @ self).log()
 
     def lplus(self, other):
+        p = self.parameters()
+        if _on_gpu(p):
+            return type(self)(_hip(self._prefix + "lplus", p, _t(other, p)))
         return type(self).exp(other) @ self
 
     def lminus(self, other):
+        p = self.parameters()
+        if _on_gpu(p, other.parameters()):
+            return _hip(self._prefix + "lminus", p, other.parameters())
         return (self @ other.inverse()).log()
 
-    plus = rplus
-    minus = rminus
+    def plus(self, other):
+        return self.rplus(other)
+
+    def minus(self, other):
+        return self.rminus(other)
 
     @classmethod
     def rjac(cls, other):
-        return cls.ljac(-_t(other))
+        o = _t(other)
+        if _on_gpu(o):
+            return _hip(cls._prefix + "rjac", o)
+        return cls.ljac(-o)
 
     @classmethod
     def rjacinv(cls, other):
-        return cls.ljacinv(-_t(other))
+        o = _t(other)
+        if _on_gpu(o):
+            return _hip(cls._prefix + "rjacinv", o)
+        return cls.ljacinv(-o)
 
     def jlog(self):
+        p = self.parameters()
+        if _on_gpu(p):
+            return _hip(self._prefix + "jlog", p)
         return type(self).rjacinv(self.log())
 
 
 class SO3(MatrixLieGroup):
     matrix_dim, parameters_dim, tangent_dim, space_dim = 3, 4, 3, 3
+    _prefix = "so3_"
 
     def __init__(self, wxyz):
         wxyz = _t(wxyz)
@@ -131,6 +193,9 @@ class SO3(MatrixLieGroup):
 
     @classmethod
     def from_rpy_radians(cls, roll, pitch, yaw):
+        r, p, y = _t(roll), _t(pitch), _t(yaw)
+        if _on_gpu(r, p, y):
+            return SO3(_hip("so3_from_rpy", torch.stack(torch.broadcast_tensors(r, p, y), -1)))
         return cls.from_z_radians(yaw) @ cls.from_y_radians(pitch) @ cls.from_x_radians(roll)
 
     @classmethod
@@ -138,6 +203,8 @@ class SO3(MatrixLieGroup):
         """Quaternion of a rotation matrix with the branch structure of mju_mat2Quat."""
         m = _t(matrix)
         assert m.shape[-2:] == (3, 3)
+        if _on_gpu(m):
+            return SO3(_hip("so3_from_matrix", m))
         m00, m11, m22 = m[..., 0, 0], m[..., 1, 1], m[..., 2, 2]
         tr = m00 + m11 + m22
         c0 = tr > 0
@@ -173,6 +240,8 @@ class SO3(MatrixLieGroup):
 
     def as_matrix(self):
         w, x, y, z = self.wxyz.unbind(-1)
+        if _on_gpu(self.wxyz):
+            return _hip("so3_as_matrix", self.wxyz)
         return torch.stack([
             torch.stack([w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)], -1),
             torch.stack([2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)], -1),
@@ -191,27 +260,39 @@ class SO3(MatrixLieGroup):
         return torch.atan2(2 * (q0 * q3 + q1 * q2), 1 - 2 * (q2**2 + q3**2))
 
     def as_rpy_radians(self):
+        if _on_gpu(self.wxyz):
+            return tuple(_hip("so3_as_rpy", self.wxyz).unbind(-1))
         return (self.compute_roll_radians(), self.compute_pitch_radians(), self.compute_yaw_radians())
 
     def inverse(self):
+        if _on_gpu(self.wxyz):
+            return SO3(_hip("so3_inverse", self.wxyz))
         return SO3(self.wxyz * torch.tensor([1.0, -1.0, -1.0, -1.0], dtype=torch.float64, device=self.wxyz.device))
 
     def normalize(self):
+        if _on_gpu(self.wxyz):
+            return SO3(_hip("so3_normalize", self.wxyz))
         return SO3(self.wxyz / torch.linalg.norm(self.wxyz, dim=-1, keepdim=True))
 
     def apply(self, target):
         t = _t(target, self.wxyz)
         assert t.shape[-1] == 3
+        if _on_gpu(self.wxyz, t):
+            return _hip("so3_apply", self.wxyz, t)
         pad = torch.cat([torch.zeros_like(t[..., :1]), t], -1)
         return _qmul(_qmul(self.wxyz, pad), self.inverse().wxyz)[..., 1:]
 
     def multiply(self, other):
+        if _on_gpu(self.wxyz, other.wxyz):
+            return SO3(_hip("so3_multiply", self.wxyz, other.wxyz))
         return SO3(_qmul(self.wxyz, other.wxyz))
 
     @classmethod
     def exp(cls, tangent):
         w = _t(tangent)
         assert w.shape[-1] == 3
+        if _on_gpu(w):
+            return SO3(_hip("so3_exp", w))
         t2 = (w * w).sum(-1)
         small = t2 < EPS
         th = torch.sqrt(torch.where(small, torch.ones_like(t2), t2))
@@ -220,6 +301,8 @@ class SO3(MatrixLieGroup):
         return SO3(torch.cat([re[..., None], im[..., None] * w], -1))
 
     def log(self):
+        if _on_gpu(self.wxyz):
+            return _hip("so3_log", self.wxyz)
         w = self.wxyz[..., 0]
         v = self.wxyz[..., 1:]
         n2 = (v * v).sum(-1)
@@ -238,6 +321,8 @@ class SO3(MatrixLieGroup):
     @classmethod
     def ljac(cls, other):
         w = _t(other)
+        if _on_gpu(w):
+            return _hip("so3_ljac", w)
         th = torch.sqrt((w * w).sum(-1))
         small = th < EPS
         t2 = th * th
@@ -250,6 +335,8 @@ class SO3(MatrixLieGroup):
     @classmethod
     def ljacinv(cls, other):
         w = _t(other)
+        if _on_gpu(w):
+            return _hip("so3_ljacinv", w)
         th = torch.sqrt((w * w).sum(-1))
         small = th < EPS
         t2 = th * th
@@ -280,6 +367,7 @@ def _getQ(c: torch.Tensor) -> torch.Tensor:
 
 class SE3(MatrixLieGroup):
     matrix_dim, parameters_dim, tangent_dim, space_dim = 4, 7, 6, 3
+    _prefix = "se3_"
 
     def __init__(self, wxyz_xyz):
         wxyz_xyz = _t(wxyz_xyz)
@@ -324,6 +412,8 @@ class SE3(MatrixLieGroup):
     def from_matrix(cls, matrix):
         m = _t(matrix)
         assert m.shape[-2:] == (4, 4)
+        if _on_gpu(m):
+            return SE3(_hip("se3_from_matrix", m))
         return cls.from_rotation_and_translation(SO3.from_matrix(m[..., :3, :3]), m[..., :3, 3])
 
     @classmethod
@@ -351,6 +441,8 @@ class SE3(MatrixLieGroup):
         return self.wxyz_xyz[..., 4:]
 
     def as_matrix(self):
+        if _on_gpu(self.wxyz_xyz):
+            return _hip("se3_as_matrix", self.wxyz_xyz)
         R = self.rotation().as_matrix()
         top = torch.cat([R, self.translation()[..., None]], -1)
         bottom = torch.zeros_like(top[..., :1, :])
@@ -361,6 +453,8 @@ class SE3(MatrixLieGroup):
     def exp(cls, tangent):
         xi = _t(tangent)
         assert xi.shape[-1] == 6
+        if _on_gpu(xi):
+            return SE3(_hip("se3_exp", xi))
         w = xi[..., 3:]
         rot = SO3.exp(w)
         t2 = (w * w).sum(-1)
@@ -374,20 +468,31 @@ class SE3(MatrixLieGroup):
         return cls.from_rotation_and_translation(rot, (V @ xi[..., :3, None])[..., 0])
 
     def inverse(self):
+        if _on_gpu(self.wxyz_xyz):
+            return SE3(_hip("se3_inverse", self.wxyz_xyz))
         Ri = self.rotation().inverse()
         return SE3.from_rotation_and_translation(Ri, -Ri.apply(self.translation()))
 
     def normalize(self):
+        if _on_gpu(self.wxyz_xyz):
+            return SE3(_hip("se3_normalize", self.wxyz_xyz))
         return SE3.from_rotation_and_translation(self.rotation().normalize(), self.translation())
 
     def apply(self, target):
-        return self.rotation().apply(target) + self.translation()
+        t = _t(target, self.wxyz_xyz)
+        if _on_gpu(self.wxyz_xyz, t):
+            return _hip("se3_apply", self.wxyz_xyz, t)
+        return self.rotation().apply(t) + self.translation()
 
     def multiply(self, other):
+        if _on_gpu(self.wxyz_xyz, other.wxyz_xyz):
+            return SE3(_hip("se3_multiply", self.wxyz_xyz, other.wxyz_xyz))
         return SE3.from_rotation_and_translation(self.rotation() @ other.rotation(),
                                                  self.rotation().apply(other.translation()) + self.translation())
 
     def log(self):
+        if _on_gpu(self.wxyz_xyz):
+            return _hip("se3_log", self.wxyz_xyz)
         w = self.rotation().log()
         t2 = (w * w).sum(-1)
         small = t2 < EPS
@@ -401,6 +506,8 @@ class SE3(MatrixLieGroup):
         return torch.cat([(Vinv @ self.translation()[..., None])[..., 0], w], -1)
 
     def adjoint(self):
+        if _on_gpu(self.wxyz_xyz):
+            return _hip("se3_adjoint", self.wxyz_xyz)
         R = self.rotation().as_matrix()
         top = torch.cat([R, skew(self.translation()) @ R], -1)
         bottom = torch.cat([torch.zeros_like(R), R], -1)
@@ -409,6 +516,8 @@ class SE3(MatrixLieGroup):
     @classmethod
     def ljac(cls, other):
         c = _t(other)
+        if _on_gpu(c):
+            return _hip("se3_ljac", c)
         w = c[..., 3:]
         small = (w * w).sum(-1) < EPS
         J = SO3.ljac(w)
@@ -418,6 +527,8 @@ class SE3(MatrixLieGroup):
     @classmethod
     def ljacinv(cls, other):
         c = _t(other)
+        if _on_gpu(c):
+            return _hip("se3_ljacinv", c)
         w = c[..., 3:]
         small = (w * w).sum(-1) < EPS
         Ji = SO3.ljacinv(w)

@@ -90,6 +90,15 @@ def build_ik(configuration, tasks: Sequence[Task], dt: float, damping: float = 1
     return Problem(o(P), o(c), None if G is None else o(G), None if h is None else o(h))
 
 
+def _limit_check(configuration, safety_break: bool) -> None:
+    """mink/solve_ik.py:99.  A single configuration, or a caller that wants the exception,
+    gets the answer now; a batch with safety_break=False only queues the check."""
+    if safety_break or not configuration.batched:
+        configuration.check_limits(safety_break=safety_break)
+    else:
+        configuration._defer_limit_check()
+
+
 def _check_solver(solver: str) -> None:
     if solver not in SUPPORTED_SOLVERS:
         raise ValueError(f"solver '{solver}' is not available; the exact active-set kernels answer to "
@@ -99,17 +108,25 @@ def _check_solver(solver: str) -> None:
 def solve_ik(configuration, tasks: Sequence[Task], dt: float, solver: str, damping: float = 1e-12,
              safety_break: bool = False, limits: Optional[Sequence[Limit]] = None, **kwargs):
     """Velocity ``v`` tangent to the current configuration(s): [nv] numpy for a single
-    configuration, [B, nv] device tensor for a batch."""
+    configuration, [B, nv] device tensor for a batch.
+
+    For a batch the call is asynchronous on the current stream and never waits for the
+    device: the limit warning (``safety_break=False``) and the solver's per-problem status are
+    kept on the device and reported by ``configuration.check()``; ``safety_break=True`` asks
+    for the exception and therefore waits for the limit check."""
     _check_solver(solver)
     limits = _resolve_limits(configuration, limits)
     if _has_custom(tasks, limits):
         # user-defined Task / Limit subclasses: assemble the dense QP and hand it to the
         # batched QP kernel (mk_qp_solve_batch)
         from .engine import qp_solve
-        configuration.check_limits(safety_break=safety_break)
+        _limit_check(configuration, safety_break)
         P, c, G, h = _assemble_with_custom(configuration, tasks, limits, dt, damping)
         x, status = qp_solve(P, c, G, h)
-        assert int((status != 0).sum()) == 0, "QP solver failed (infeasible limits or non-finite input)"
+        if configuration.batched:
+            configuration._defer_status(status)
+        else:
+            assert int((status != 0).sum()) == 0, "QP solver failed (infeasible limits or non-finite input)"
         return configuration._out(x / dt)
     if not configuration.batched:
         # One configuration: the limit check rides along with the solve and one copy brings
@@ -120,10 +137,12 @@ def solve_ik(configuration, tasks: Sequence[Task], dt: float, solver: str, dampi
             configuration._report_limit_violation(0, first, 1, safety_break)
         assert status == 0, "QP solver failed (infeasible limits or non-finite input)"
         return v
-    configuration.check_limits(safety_break=safety_break)
+    # A batch: nothing here waits for the device.  The limit check (unless the caller asked for
+    # the exception) and the solver status stay on the device until `configuration.check()`.
+    _limit_check(configuration, safety_break)
     prob, targets = get_problem(configuration, tasks, _resolve_limits(configuration, limits))
     v, status = prob.solve(configuration.q_tensor, targets, dt, damping)
-    assert int((status != 0).sum()) == 0, "QP solver failed (infeasible limits or non-finite input)"
+    configuration._defer_status(status)
     return v
 
 
@@ -149,6 +168,6 @@ def solve_ik_iterate(configuration, tasks: Sequence[Task], dt: float, solver: st
         return res
     res = prob.iterate_(configuration.q_tensor, targets, dt, damping, max_iters, pos_threshold, ori_threshold,
                         want_v=True)
-    assert int((res["status"] != 0).sum()) == 0, "QP solver failed (infeasible limits or non-finite input)"
-    return {k: configuration._out(v) for k, v in res.items()}
+    configuration._defer_status(res["status"])     # also returned: callers may look at it themselves
+    return dict(res)
 

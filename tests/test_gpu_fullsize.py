@@ -162,3 +162,34 @@ def test_config5_shard_size_fixed_point_and_invariance(env):
     prob5.iterate_(qb, tg0[lo:lo + n].contiguous(), W.DT, W.DAMPING, 50)
     assert int(ra["status"].abs().sum()) == 0
     assert torch.equal(qb, qa[lo:lo + n])
+
+
+def test_config5_full_batch_one_launch_and_shard_invariance(env):
+    """The whole 1 048 576-problem batch of benchmark config 5 (seed 4, the rows bench.py
+    uses) x 50 iterated steps as ONE launch on one GPU; the rows that rank 5 of 8 would own
+    (sharding.shard_bounds), solved alone from inputs generated for that shard only, are
+    bit-identical -- which is what makes the N-GPU runs the same job as the 1-GPU run."""
+    from mink_amd import sharding as S
+    from mink_amd.engine import DeviceProblem
+    model, dm = env
+    total, K, seed = 1 << 20, 50, 4
+    prob = DeviceProblem(dm, W.task_specs(model, False), W.limit_specs(model, True))
+    assert prob.fused
+    site = model.site_id("pinch_site")
+    q0, qs = S.global_rows(model, seed, 0, total)
+    q = torch.tensor(q0, device=DEV)
+    tg = dm.frame_pose(torch.tensor(qs, device=DEV), L.FRAME_TYPES["site"], site)
+    res = prob.iterate_(q, tg, W.DT, W.DAMPING, K)
+    assert int(res["status"].abs().sum()) == 0 and int((res["iters"] != K).sum()) == 0
+    assert bool(torch.isfinite(q).all())
+    lo, hi = S.shard_bounds(total, 5, 8)
+    assert (lo, hi) == (5 * 131072, 6 * 131072)
+    q0s, qss = S.global_rows(model, seed, lo, hi)
+    np.testing.assert_array_equal(q0s, q0[lo:hi])
+    qsh = torch.tensor(q0s, device=DEV)
+    tgs = dm.frame_pose(torch.tensor(qss, device=DEV), L.FRAME_TYPES["site"], site)
+    rs = prob.iterate_(qsh, tgs, W.DT, W.DAMPING, K)
+    assert torch.equal(qsh, q[lo:hi]) and torch.equal(rs["err"], res["err"][lo:hi])
+    # ragged split (world 3) covers every row exactly once
+    b3 = [S.shard_bounds(total, r, 3) for r in range(3)]
+    assert b3[0][0] == 0 and b3[-1][1] == total and all(b3[i][1] == b3[i + 1][0] for i in range(2))
