@@ -158,7 +158,7 @@ def cpu_baseline(model, q0_np, targets_np, gpu_q_final):
             for _ in range(20):
                 cfg.integrate_inplace(o.solve_ik(cfg, tasks, W.DT, damping=W.DAMPING, limits=limits), W.DT)
                 solves += 1
-                e = ft.compute_error(cfg)
+                e = ft.error(cfg)
                 if np.linalg.norm(e[:3]) <= 1e-4 and np.linalg.norm(e[3:]) <= 1e-4:
                     break
             problems += 1

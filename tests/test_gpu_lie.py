@@ -173,7 +173,7 @@ def test_axioms_at_size(G):
     close(a @ ident, a)
     close(a @ a.inverse(), ident)
     close((a @ b) @ c3, a @ (b @ c3))
-    close(a.inverse().inverse(), a, 0.0)
+    close(a.inverse().inverse(), a, 1e-14)
     close(G.from_matrix(a.as_matrix()), a)
     close(G.exp(a.log()), a)
     close(a.rplus(b.rminus(a)), b)
