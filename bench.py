@@ -280,6 +280,32 @@ def other_workloads(model, dm, prob, q0, targets, out, device, barrier):
              "<= 20 iterations with the 1e-4 / 1e-4 exit test (interactive_scripts/teleop_mouse.py:105-121); "
              "solves counted as executed")
     del qn, tn
+    # the same loop at 2^20 problems, where throughput rather than the slowest wave counts: lanes
+    # stream through their chunk's problems (the library's choice at this size), and, for scale,
+    # the same launch with one block per 64 problems
+    Bl = 1 << 20
+    ql0 = q0[:Bl] if q0.shape[0] >= Bl else q0.repeat((Bl + q0.shape[0] - 1) // q0.shape[0], 1)[:Bl].contiguous()
+    poses = dm.frame_pose(ql0, L.FRAME_TYPES["site"], model.site_id("pinch_site")).cpu().numpy()
+    tl = torch.tensor(W.offset_targets(poses, np.random.default_rng(SEED + 2)), device=device)
+    ql = [ql0.clone() for _ in range(4)]
+    ol = dict(iters=torch.empty(Bl, dtype=torch.int32, device=device),
+              err=torch.empty((Bl, 6), dtype=torch.float64, device=device),
+              status=torch.empty(Bl, dtype=torch.int32, device=device))
+    big = {}
+    for name, knob in (("streaming", None), ("block_per_64", "0")):
+        if knob is not None:
+            os.environ["MK_FUSED_STREAM_BLOCKS"] = knob
+        for b in ql:
+            b.copy_(ql0)
+        wl, el = time_launches(lambda i: pn.iterate_(ql[i], tl, W.DT, W.DAMPING, 20, 1e-4, 1e-4, out=ol), 3, 1, barrier)
+        os.environ.pop("MK_FUSED_STREAM_BLOCKS", None)
+        st = loop_stats(ol)
+        big[name] = dict(ms_per_launch=1e3 * el / 3, solves_per_s=Bl * st["mean_solves"] * 3 / wl,
+                         problems_per_s=Bl * 3 / wl)
+        big.update(fraction_converged=st["fraction_converged"], mean_solves=st["mean_solves"],
+                   max_solves=st["max_solves"])
+    extra["near_target_loop_B1048576"] = big
+    del ql, tl, ql0
     # the arm + base only model (mobile_kinova.xml, nq = nv = 10), same tasks and limits
     mk_model = load_builtin("mobile_kinova")
     mk_dm = DeviceModel(mk_model, device)

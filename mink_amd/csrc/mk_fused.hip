@@ -19,6 +19,8 @@
 #include "mk_device.h"
 #include "mk_generic.h"
 
+#include <cstdlib>
+
 // One wave per workgroup; register budget / occupancy target of the fused kernels.
 #ifndef MK_KERNEL_ATTR
 #define MK_KERNEL_ATTR __launch_bounds__(64)
@@ -161,7 +163,9 @@ MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const do
   }
   // ---- phase 1 ----
   bool settled = bad;
-  for (int round = 0; round < kGuessRounds + N + 2; ++round) {
+  // (the cap is the same for warm and cold lanes, so the loop stays wave-uniform when the two
+  // kinds share a wave; a lane is settled at most N rounds after its additions stop)
+  for (int round = 0; round < 6 + N + 2; ++round) {
     if (!settled) {
       MK_STAT(1);
       // H is re-read from LDS every round on purpose: hoisting the loads would pin the
@@ -693,6 +697,117 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
   tile_copy<false>(tile, stride, q + base * nq, rows, nq);
 }
 
+// The callers' loop for batches much larger than the machine, with early exit: a persistent
+// wave owns a contiguous chunk of problems and every LANE works through problems of the
+// chunk one after the other -- a lane whose problem has left the loop (converged, or out of
+// iterations) writes it back and takes the next one, so a slow problem holds one lane, not
+// 64.  The arithmetic of a problem is the same instruction sequence as in
+// fused_iterate_kernel, whatever lane and company it runs in: results are bit-identical.
+// The next problem index is wave-uniform state (one wave per block), so handing out
+// problems needs neither atomics nor memory.
+template <int NC>
+__global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __restrict__ D_arg,
+                                                           double* __restrict__ q,
+                                                           const double* __restrict__ targets, int target_stride,
+                                                           double dt, double damping, int B, int chunk, int max_iters,
+                                                           double pos_tol, double ori_tol,
+                                                           double* __restrict__ v_out, int32_t* __restrict__ iters_out,
+                                                           double* __restrict__ err_out,
+                                                           int32_t* __restrict__ status_out) {
+  const MkFusedDesc* D = D_arg;
+  extern __shared__ double tile[];
+  const int nq = D->nq, nv = D->nv;
+  const int stride = nq | 1;
+  const double inv_dt = 1.0 / dt;
+  const int lane = threadIdx.x;
+  double* row = tile + lane * stride;
+  double* hlds = tile + 64 * stride + lane;
+  long next = (long)blockIdx.x * chunk;                       // wave-uniform: first problem not yet handed out
+  const long last = min((long)B, next + (long)chunk);
+  const bool sync_rows = D->any_posture_lm != 0;
+  long pid = -1;                                              // -1: nothing yet, -2: chunk exhausted
+  bool live = false, input_bad = false;
+  double qc[NC], x[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) { qc[k] = 0.0; x[k] = 0.0; }
+  Q4 Qt = Q4{1, 0, 0, 0};
+  V3 pt = v3(0, 0, 0);
+  Twist e = Twist{v3(0, 0, 0), v3(0, 0, 0)};
+  int status = 0, iters = 0, it = 0;
+  uint32_t act = 0u, upper = 0u;
+  for (;;) {
+    const bool want = !live && pid != -2;
+    const uint64_t wm = __ballot(want);
+    if (wm != 0ull) {   // wave-uniform
+      if (want && pid >= 0) {
+        // the finished problem goes back to its rows
+        store_chain_q<NC>(D, row, qc);
+        double* qg = q + pid * nq;
+        for (int i = 0; i < nq; ++i) qg[i] = row[i];
+        if (v_out) {
+          double* vr = v_out + pid * nv;
+#pragma unroll
+          for (int k = 0; k < NC; ++k)
+            if (D->seg_dof[k] >= 0) vr[D->seg_dof[k]] = x[k];
+        }
+        status_out[pid] = status;
+        if (iters_out) iters_out[pid] = iters;
+        if (err_out) {
+          double* eo = err_out + pid * 6;
+          eo[0] = e.v.x; eo[1] = e.v.y; eo[2] = e.v.z; eo[3] = e.w.x; eo[4] = e.w.y; eo[5] = e.w.z;
+        }
+      }
+      const long mine = next + __popcll(wm & ((1ull << lane) - 1ull));
+      next += __popcll(wm);
+      if (want) {
+        if (mine < last) {
+          pid = mine;
+          const double* qg = q + pid * nq;
+          for (int i = 0; i < nq; ++i) row[i] = qg[i];
+          const double* tg = targets + pid * target_stride + D->target_off;
+          Qt = Q4{tg[0], tg[1], tg[2], tg[3]};
+          pt = v3(tg[4], tg[5], tg[6]);
+          load_chain_q<NC>(D, row, qc);
+#pragma unroll
+          for (int k = 0; k < NC; ++k) x[k] = 0.0;
+          input_bad = rest_nonfinite(D, row);
+          e = Twist{v3(0, 0, 0), v3(0, 0, 0)};
+          status = 0; iters = 0; it = 0;
+          act = 0u; upper = 0u;
+          live = true;
+        } else {
+          pid = -2;
+        }
+      }
+    }
+    if (__ballot(live) == 0ull) break;
+    const MkFusedDesc* __restrict__ Di = D_arg + mk_opaque_zero();   // same descriptor, re-read per pass
+    if (live) {
+      ChainJac<NC> cj;
+      chain_jac<NC>(Di, qc, Qt, pt, cj);
+      e = cj.e;
+      const bool conv = it > 0 && sqrt(dot(e.v, e.v)) <= pos_tol && sqrt(dot(e.w, e.w)) <= ori_tol;
+      if (conv || it == max_iters) {
+        live = false;
+      } else {
+        double* vrow = v_out ? v_out + pid * nv : nullptr;
+        const int st = solve_problem<NC, true>(Di, row, qc, cj, dt, inv_dt, damping, x, vrow, act, upper, it > 0, hlds, 64,
+                                               input_bad);
+        status = max(status, st);
+        iters = it + 1;
+        ++it;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          const double vk = x[k] * inv_dt;
+          x[k] = vk;
+          qc[k] = qc[k] + dt * vk;
+        }
+        if (sync_rows) store_chain_q<NC>(Di, row, qc);
+      }
+    }
+  }
+}
+
 // LinearWaypointReach.step (envs/robot_utils.py:131-160) for the current pose (Qc, tc) and
 // the goal (Qg, pg): the commanded pose (Qt, pt) -- a step of at most pos_step along the
 // straight line to the goal position (the goal itself once within pos_thr), half-way along
@@ -848,6 +963,34 @@ static hipError_t launch_iterate(const MkFusedDesc* d_desc, int nq, double* q, c
   return hipGetLastError();
 }
 
+// Wave slots of the current device at one wave per SIMD (the occupancy of these kernels).
+static int wave_slots() {
+  static std::atomic<int> cached[32];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 1024;
+  int v = cached[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    v = 4 * cus;
+    cached[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
+template <int NC>
+static hipError_t launch_iterate_stream(const MkFusedDesc* d_desc, int nq, double* q, const double* targets,
+                                        int target_stride, double dt, double damping, int B, int blocks, int max_iters,
+                                        double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
+                                        int32_t* status, hipStream_t stream) {
+  const int chunk = (B + blocks - 1) / blocks;
+  const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
+  if (hipError_t e = allow_lds<fused_iterate_stream_kernel<NC>>(lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(fused_iterate_stream_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
+                     target_stride, dt, damping, B, chunk, max_iters, pos_tol, ori_tol, v, iters, err, status);
+  return hipGetLastError();
+}
+
 hipError_t mk_fused_launch_step(int nc, const MkFusedDesc* d_desc, int nq, const double* q, const double* targets,
                                 int target_stride, double dt, double damping, int B, double* v, int32_t* status,
                                 hipStream_t stream) {
@@ -864,6 +1007,29 @@ hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, do
                                    int target_stride, double dt, double damping, int B, int max_iters,
                                    double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
                                    int32_t* status, hipStream_t stream) {
+  // With an exit test and more problems than twice the lanes of the machine, lanes stream
+  // through the problems of a chunk (one persistent wave per slot); otherwise one block of 64
+  // problems per wave with coalesced tile copies.
+  int slots = wave_slots();
+  bool stream_path = (long)B >= 2L * 64 * slots;
+  // MK_FUSED_STREAM_BLOCKS=<n> (tests, tuning): take the streaming kernel with n persistent
+  // waves whatever the batch size; 0 switches it off
+  if (const char* ev = getenv("MK_FUSED_STREAM_BLOCKS")) {
+    const int n = atoi(ev);
+    stream_path = n > 0;
+    if (n > 0) slots = n;
+  }
+  if (stream_path && (pos_tol >= 0.0 && ori_tol >= 0.0) && max_iters > 1) {
+    switch (nc) {
+#define MK_CASE(N)                                                                                              \
+  case N:                                                                                                       \
+    return launch_iterate_stream<N>(d_desc, nq, q, targets, target_stride, dt, damping, B, slots, max_iters,  \
+                                    pos_tol, ori_tol, v, iters, err, status, stream);
+      MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
+#undef MK_CASE
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (nc) {
 #define MK_CASE(N)                                                                                         \
   case N:                                                                                                  \
