@@ -333,32 +333,35 @@ def other_workloads(model, dm, prob, q0, targets, out, device, barrier):
         "solves_per_s": B4 * 3 / w4, "ms_per_launch": 1e3 * e4 / 3,
         "status_nonzero": int((s4 != 0).sum().item())}
     del q4, tg4, v4, s4
-    # kinematic move_to rollouts (waypoint generator + the callers' IK loop per waypoint step)
+    # kinematic move_to rollouts (waypoint generator + the callers' IK loop per waypoint step) as one launch
     import mink_amd as mk
-    Br = 65536
-    rq = q0[:Br].clone()
-    rcfg = mk.Configuration(model, rq, device=device)
-    start = rcfg.get_transform_frame_to_world("pinch_site", "site")
-    g = torch.Generator(device="cpu").manual_seed(SEED)
-    goal_pos = start.translation() + (torch.rand((Br, 3), generator=g, dtype=torch.float64) * 0.3 - 0.15).to(device)
-    goal_rot = start.rotation() @ mk.SO3.exp((torch.rand((Br, 3), generator=g, dtype=torch.float64) * 0.8 - 0.4).to(device))
     ftask = mk.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0)
     ptask = mk.PostureTask(model, cost=W.posture_cost(model))
     ptask.set_target(W.home_q(model))
     wcfg = mk.LinearWaypointReachConfig(0.01, 0.08, 0.05, 0.3)
-    mk.move_to(mk.Configuration(model, rq[:4096].clone(), device=device), ftask, [ftask, ptask],
-               goal_pos[:4096], mk.SO3(goal_rot.wxyz[:4096]), wcfg, max_steps=50)   # warm-up
-    torch.cuda.synchronize()
-    tr = time.perf_counter()
-    ro = mk.move_to(rcfg, ftask, [ftask, ptask], goal_pos, goal_rot, wcfg, max_steps=50)
-    torch.cuda.synchronize()
-    tr = time.perf_counter() - tr
-    extra["move_to_rollouts_B65536"] = {
-        "rollouts_per_s": Br / tr, "seconds": tr, "fraction_reached": float(ro["reached"].double().mean().item()),
-        "mean_waypoint_steps": float(ro["steps"].double().mean().item()),
-        "ik_solves_per_s": float(ro["solves"].sum().item()) / tr,
-        "note": "kinematic part of the reference's move_to (waypoint generator + <=20-iteration IK loop per "
-                "step, default ConfigurationLimit) as one launch (mk_move_to_batch), physics excluded"}
+    for Br in (65536, 262144):
+        rq = q0[:Br].clone()
+        rcfg = mk.Configuration(model, rq, device=device)
+        start = rcfg.get_transform_frame_to_world("pinch_site", "site")
+        g = torch.Generator(device="cpu").manual_seed(SEED)
+        goal_pos = start.translation() + (torch.rand((Br, 3), generator=g, dtype=torch.float64) * 0.3 - 0.15).to(device)
+        goal_rot = start.rotation() @ mk.SO3.exp((torch.rand((Br, 3), generator=g, dtype=torch.float64) * 0.8 - 0.4).to(device))
+        mk.move_to(mk.Configuration(model, rq[:4096].clone(), device=device), ftask, [ftask, ptask],
+                   goal_pos[:4096], mk.SO3(goal_rot.wxyz[:4096]), wcfg, max_steps=50)   # warm-up
+        torch.cuda.synchronize()
+        tr = time.perf_counter()
+        ro = mk.move_to(rcfg, ftask, [ftask, ptask], goal_pos, goal_rot, wcfg, max_steps=50)
+        torch.cuda.synchronize()
+        tr = time.perf_counter() - tr
+        extra[f"move_to_rollouts_B{Br}"] = {
+            "rollouts_per_s": Br / tr, "seconds": tr, "fraction_reached": float(ro["reached"].double().mean().item()),
+            "mean_waypoint_steps": float(ro["steps"].double().mean().item()),
+            "ik_solves_per_s": float(ro["solves"].sum().item()) / tr,
+            "mean_solves_per_rollout": float(ro["solves"].double().mean().item()),
+            "max_solves_per_rollout": int(ro["solves"].max().item()),
+            "note": "kinematic part of the reference's move_to (waypoint generator + <=20-iteration IK loop per "
+                    "step, default ConfigurationLimit) as one launch (mk_move_to_batch), physics excluded; the "
+                    "launch lasts as long as its slowest rollout (max_solves_per_rollout sequential solves)"}
     return extra
 
 

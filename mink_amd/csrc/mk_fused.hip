@@ -19,6 +19,7 @@
 #include "mk_device.h"
 #include "mk_generic.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 // One wave per workgroup; register budget / occupancy target of the fused kernels.
@@ -306,10 +307,11 @@ struct ChainJac {
 // intermediates.  Hinges, slides and padding slots share one instruction stream (the
 // `hinge` factor of the slot selects), so the pass is straight-line code.
 template <int NC>
-MK_DEV void chain_jac(const MkFusedDesc* __restrict__ D, const double (&qc)[NC], Q4 Qt, V3 pt, ChainJac<NC>& cj) {
-  Q4 Q = Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]};
-  V3 t = v3(D->post_pos[0], D->post_pos[1], D->post_pos[2]);
-  M3 R = q2m(Q);
+MK_DEV void chain_jac_pose(const MkFusedDesc* __restrict__ D, const double (&qc)[NC], ChainJac<NC>& cj, Q4& Q, V3& t,
+                           M3& R) {
+  Q = Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]};
+  t = v3(D->post_pos[0], D->post_pos[1], D->post_pos[2]);
+  R = q2m(Q);
   MkSegC s = D->segc[NC - 1];
 #pragma unroll
   for (int k = NC - 1; k >= 0; --k) {
@@ -343,7 +345,19 @@ MK_DEV void chain_jac(const MkFusedDesc* __restrict__ D, const double (&qc)[NC],
     s = nx;
   }
   // (Q, t, R) is now the pose of the task frame in the world
-  cj.e = se3_log(qmul(qconj(Q), Qt), mulT(R, pt - t));
+}
+
+// Frame-task error e = log(T_wb^-1 T_wt) (mink/tasks/frame_task.py:95-122) of the frame at
+// (Q, t, R = mat(Q)) for the target (Qt, pt).
+MK_DEV Twist frame_error(Q4 Q, V3 t, const M3& R, Q4 Qt, V3 pt) { return se3_log(qmul(qconj(Q), Qt), mulT(R, pt - t)); }
+
+template <int NC>
+MK_DEV void chain_jac(const MkFusedDesc* __restrict__ D, const double (&qc)[NC], Q4 Qt, V3 pt, ChainJac<NC>& cj) {
+  Q4 Q;
+  V3 t;
+  M3 R;
+  chain_jac_pose<NC>(D, qc, cj, Q, t, R);
+  cj.e = frame_error(Q, t, R, Qt, pt);
 }
 
 // World pose (Q, t) of the task frame alone: the recursion of chain_jac without columns.
@@ -697,6 +711,26 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
   tile_copy<false>(tile, stride, q + base * nq, rows, nq);
 }
 
+// Per-lane copy of n doubles with the loads of eight elements in flight together (a plain
+// loop waits for every element's round trip in turn; nothing else hides that latency at one
+// wave per SIMD).
+MK_DEV void lane_copy(double* __restrict__ dst, const double* __restrict__ src, int n) {
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    double t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = src[i + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[i + k] = t[k];
+  }
+  double t[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) t[k] = (i + k < n) ? src[i + k] : 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (i + k < n) dst[i + k] = t[k];
+}
+
 // The callers' loop for batches much larger than the machine, with early exit: a persistent
 // wave owns a contiguous chunk of problems and every LANE works through problems of the
 // chunk one after the other -- a lane whose problem has left the loop (converged, or out of
@@ -709,8 +743,8 @@ template <int NC>
 __global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __restrict__ D_arg,
                                                            double* __restrict__ q,
                                                            const double* __restrict__ targets, int target_stride,
-                                                           double dt, double damping, int B, int chunk, int max_iters,
-                                                           double pos_tol, double ori_tol,
+                                                           double dt, double damping, int B, int chunk, int refill_min,
+                                                           int max_iters, double pos_tol, double ori_tol,
                                                            double* __restrict__ v_out, int32_t* __restrict__ iters_out,
                                                            double* __restrict__ err_out,
                                                            int32_t* __restrict__ status_out) {
@@ -738,12 +772,13 @@ __global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __
   for (;;) {
     const bool want = !live && pid != -2;
     const uint64_t wm = __ballot(want);
-    if (wm != 0ull) {   // wave-uniform
+    // lanes are handed new problems once enough of them wait (or nothing else is left to do):
+    // a hand-over costs the wave a memory round trip whatever the number of lanes in it
+    if (wm != 0ull && (__popcll(wm) >= refill_min || __ballot(live) == 0ull)) {   // wave-uniform
       if (want && pid >= 0) {
         // the finished problem goes back to its rows
         store_chain_q<NC>(D, row, qc);
-        double* qg = q + pid * nq;
-        for (int i = 0; i < nq; ++i) qg[i] = row[i];
+        lane_copy(q + pid * nq, row, nq);
         if (v_out) {
           double* vr = v_out + pid * nv;
 #pragma unroll
@@ -762,8 +797,7 @@ __global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __
       if (want) {
         if (mine < last) {
           pid = mine;
-          const double* qg = q + pid * nq;
-          for (int i = 0; i < nq; ++i) row[i] = qg[i];
+          lane_copy(row, q + pid * nq, nq);
           const double* tg = targets + pid * target_stride + D->target_off;
           Qt = Q4{tg[0], tg[1], tg[2], tg[3]};
           pt = v3(tg[4], tg[5], tg[6]);
@@ -827,18 +861,26 @@ MK_DEV bool waypoint_step(Q4 Qc, V3 tc, Q4 Qg, V3 pg, double pos_thr, double pos
   return pos_reached && sqrt(dot(eul, eul)) < rot_thr;
 }
 
-// Waypoint reaching (envs/mj_env.py:193-276 with envs/robot_utils.py:113-160) as one launch:
-// per outer step the pose of the task frame, the waypoint generator (bounded linear step
-// towards the goal position, half-way slerp towards the goal orientation, reached test on
-// the position distance and the x-y-z Euler angles of goal * current^-1), then the callers'
-// IK loop towards the commanded pose.  A problem stops after the step in which its
-// generator reports the goal reached.
+// Waypoint reaching (envs/mj_env.py:193-276 with envs/robot_utils.py:113-160) as one launch.
+// Per problem the reference runs, for up to max_steps outer steps: the pose of the task
+// frame; the waypoint generator (bounded linear step towards the goal position, half-way
+// slerp towards the goal orientation, reached test on the position distance and the x-y-z
+// Euler angles of goal * current^-1); then the callers' IK loop towards the commanded pose;
+// and stops after the step in which the generator reported the goal reached.
+//
+// Here the two nested loops of a problem are one flat sequence of "ticks" (one IK iteration
+// each), and every lane runs its own sequence: a tick evaluates the chain once, closes the
+// lane's outer step if its IK loop has ended on this pose (exit test or iteration cap),
+// opens the next one on the same pose (waypoint generator), and solves.  Lanes whose problem
+// is finished take the next problem of the wave's chunk, as in fused_iterate_stream_kernel.
+// A problem's arithmetic does not depend on the lane or the company it runs in.
 template <int NC>
 __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restrict__ D_arg, double* __restrict__ q,
                                                     const double* __restrict__ goals, double dt, double damping,
-                                                    int B, int max_steps, int max_iters, double pos_tol,
-                                                    double ori_tol, double wp_pos_thr, double wp_pos_step,
-                                                    double wp_rot_thr, int32_t* __restrict__ steps_out,
+                                                    int B, int chunk, int refill_min, int max_steps, int max_iters,
+                                                    double pos_tol, double ori_tol, double wp_pos_thr,
+                                                    double wp_pos_step, double wp_rot_thr,
+                                                    int32_t* __restrict__ steps_out,
                                                     int32_t* __restrict__ reached_out,
                                                     int32_t* __restrict__ solves_out,
                                                     int32_t* __restrict__ status_out) {
@@ -848,83 +890,105 @@ __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restric
   const int stride = nq | 1;
   const double inv_dt = 1.0 / dt;
   const int lane = threadIdx.x;
-  const long base = (long)blockIdx.x * 64;
-  const int rows = (int)min((long)64, (long)B - base);
-  tile_copy<true>(tile, stride, q + base * nq, rows, nq);
-  __syncthreads();
-  const bool valid = lane < rows;
   double* row = tile + lane * stride;
   double* hlds = tile + 64 * stride + lane;
-  if (!valid) {
-    for (int i = 0; i < nq; ++i) row[i] = tile[i];
-  }
-  const long pb = valid ? base + lane : base;
-  const double* gp = goals + pb * 7;
-  const Q4 Qg = Q4{gp[0], gp[1], gp[2], gp[3]};
-  const V3 pg = v3(gp[4], gp[5], gp[6]);
-  double qc[NC], x[NC];
-  load_chain_q<NC>(D, row, qc);
-#pragma unroll
-  for (int k = 0; k < NC; ++k) x[k] = 0.0;
+  long next = (long)blockIdx.x * chunk;
+  const long last = min((long)B, next + (long)chunk);
   const bool sync_rows = D->any_posture_lm != 0;
-  const bool input_bad = rest_nonfinite(D, row);
-  int status = 0, steps = 0, solves = 0;
-  bool finished = false, reached = false;
-  uint32_t act = 0u, upper = 0u;
-  for (int s = 0; s < max_steps; ++s) {
-    // ---- waypoint generator on the current pose ----
-    Q4 Qt;
-    V3 pt;
-    bool now;
-    {
-      const MkFusedDesc* __restrict__ Dw = D_arg + mk_opaque_zero();
-      Q4 Qc;
-      V3 tc;
-      chain_pose<NC>(Dw, qc, Qc, tc);
-      now = waypoint_step(Qc, tc, Qg, pg, wp_pos_thr, wp_pos_step, wp_rot_thr, Qt, pt);
-    }
-    // ---- the callers' IK loop towards the commanded pose ----
-    bool done = finished;
-    int iters = 0;
-    for (int it = 0; it <= max_iters; ++it) {
-      const MkFusedDesc* __restrict__ Di = D_arg + mk_opaque_zero();
-      if (!done) {
-        ChainJac<NC> cj;
-        chain_jac<NC>(Di, qc, Qt, pt, cj);
-        const bool conv = it > 0 && sqrt(dot(cj.e.v, cj.e.v)) <= pos_tol && sqrt(dot(cj.e.w, cj.e.w)) <= ori_tol;
-        if (conv || it == max_iters) {
-          done = true;
-        } else {
-          const int st = solve_problem<NC, true>(Di, row, qc, cj, dt, inv_dt, damping, x, nullptr, act, upper,
-                                                 it > 0 || s > 0, hlds, 64, input_bad);
-          status = max(status, st);
-          iters = it + 1;
+  long pid = -1;                                   // -1: nothing yet, -2: chunk exhausted
+  bool live = false, input_bad = false, now = false, reached = false, in_step = false;
+  double qc[NC], x[NC];
 #pragma unroll
-          for (int k = 0; k < NC; ++k) qc[k] = qc[k] + dt * (x[k] * inv_dt);
-          if (sync_rows) store_chain_q<NC>(Di, row, qc);
+  for (int k = 0; k < NC; ++k) { qc[k] = 0.0; x[k] = 0.0; }
+  Q4 Qg = Q4{1, 0, 0, 0}, Qt = Q4{1, 0, 0, 0};
+  V3 pg = v3(0, 0, 0), pt = v3(0, 0, 0);
+  int status = 0, steps = 0, solves = 0, it = 0;
+  uint32_t act = 0u, upper = 0u;
+  for (;;) {
+    const bool want = !live && pid != -2;
+    const uint64_t wm = __ballot(want);
+    if (wm != 0ull && (__popcll(wm) >= refill_min || __ballot(live) == 0ull)) {   // wave-uniform
+      if (want && pid >= 0) {
+        store_chain_q<NC>(D, row, qc);
+        lane_copy(q + pid * nq, row, nq);
+        status_out[pid] = status;
+        if (steps_out) steps_out[pid] = steps;
+        if (reached_out) reached_out[pid] = reached ? 1 : 0;
+        if (solves_out) solves_out[pid] = solves;
+      }
+      const long mine = next + __popcll(wm & ((1ull << lane) - 1ull));
+      next += __popcll(wm);
+      if (want) {
+        if (mine < last) {
+          pid = mine;
+          lane_copy(row, q + pid * nq, nq);
+          const double* gp = goals + pid * 7;
+          Qg = Q4{gp[0], gp[1], gp[2], gp[3]};
+          pg = v3(gp[4], gp[5], gp[6]);
+          load_chain_q<NC>(D, row, qc);
+          input_bad = rest_nonfinite(D, row);
+          status = 0; steps = 0; solves = 0; it = 0;
+          act = 0u; upper = 0u;
+          now = false; reached = false; in_step = false;
+          live = max_steps > 0;     // no outer step at all: the problem goes straight back
+        } else {
+          pid = -2;
         }
       }
-      if (mk_wave_none(!done)) break;
     }
-    if (!finished) {
-      ++steps;
-      solves += iters;
-      if (now) {
-        reached = true;
-        finished = true;
+    if (__ballot(live) == 0ull) {
+      if (__ballot(!live && pid >= 0) == 0ull) break;   // nothing left to write back either
+      continue;
+    }
+    const MkFusedDesc* __restrict__ Di = D_arg + mk_opaque_zero();
+    if (live) {
+      ChainJac<NC> cj;
+      Q4 Q;
+      V3 t;
+      M3 R;
+      chain_jac_pose<NC>(Di, qc, cj, Q, t, R);
+      // does the IK loop of the lane's current outer step end on this pose?
+      bool begin = !in_step;
+      if (in_step) {
+        cj.e = frame_error(Q, t, R, Qt, pt);
+        const bool conv = it > 0 && sqrt(dot(cj.e.v, cj.e.v)) <= pos_tol && sqrt(dot(cj.e.w, cj.e.w)) <= ori_tol;
+        if (conv || it == max_iters) {
+          ++steps;
+          if (now) {
+            reached = true;
+            live = false;
+          } else if (steps == max_steps) {
+            live = false;
+          } else {
+            begin = true;
+          }
+        }
+      }
+      if (begin) {
+        // the next outer step opens on the same pose: waypoint generator, then the error
+        // towards the new command
+        now = waypoint_step(Q, t, Qg, pg, wp_pos_thr, wp_pos_step, wp_rot_thr, Qt, pt);
+        it = 0;
+        in_step = true;
+        if (max_iters == 0) {
+          // no IK iteration per step: the pose never changes, so every step repeats this one
+          if (now) { ++steps; reached = true; } else { steps = max_steps; }
+          live = false;
+        }
+        cj.e = frame_error(Q, t, R, Qt, pt);
+      }
+      if (live) {
+        const int st = solve_problem<NC, true>(Di, row, qc, cj, dt, inv_dt, damping, x, nullptr, act, upper,
+                                               it > 0 || steps > 0, hlds, 64, input_bad);
+        status = max(status, st);
+        ++it;
+        ++solves;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) qc[k] = qc[k] + dt * (x[k] * inv_dt);
+        if (sync_rows) store_chain_q<NC>(Di, row, qc);
       }
     }
-    if (mk_wave_none(!finished)) break;
   }
-  store_chain_q<NC>(D, row, qc);
-  if (valid) {
-    status_out[pb] = status;
-    if (steps_out) steps_out[pb] = steps;
-    if (reached_out) reached_out[pb] = reached ? 1 : 0;
-    if (solves_out) solves_out[pb] = solves;
-  }
-  __syncthreads();
-  tile_copy<false>(tile, stride, q + base * nq, rows, nq);
 }
 
 }  // namespace
@@ -984,10 +1048,13 @@ static hipError_t launch_iterate_stream(const MkFusedDesc* d_desc, int nq, doubl
                                         double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
                                         int32_t* status, hipStream_t stream) {
   const int chunk = (B + blocks - 1) / blocks;
+  int refill_min = 16;
+  if (const char* ev = getenv("MK_FUSED_STREAM_REFILL")) refill_min = atoi(ev);   // tuning
   const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
   if (hipError_t e = allow_lds<fused_iterate_stream_kernel<NC>>(lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(fused_iterate_stream_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
-                     target_stride, dt, damping, B, chunk, max_iters, pos_tol, ori_tol, v, iters, err, status);
+                     target_stride, dt, damping, B, chunk, refill_min, max_iters, pos_tol, ori_tol, v, iters, err,
+                     status);
   return hipGetLastError();
 }
 
@@ -1046,12 +1113,20 @@ static hipError_t launch_move_to(const MkFusedDesc* d_desc, int nq, double* q, c
                                  double damping, int B, int max_steps, int max_iters, double pos_tol, double ori_tol,
                                  double wp_pos_thr, double wp_pos_step, double wp_rot_thr, int32_t* steps,
                                  int32_t* reached, int32_t* solves, int32_t* status, hipStream_t stream) {
-  const int blocks = (B + 63) / 64;
+  // one persistent wave per wave slot of the device at most; with fewer problems than lanes
+  // every lane gets exactly one problem
+  int slots = wave_slots();
+  if (const char* ev = getenv("MK_FUSED_STREAM_BLOCKS"))
+    if (atoi(ev) > 0) slots = atoi(ev);
+  const int blocks = std::max(1, std::min((B + 63) / 64, slots));
+  const int chunk = (B + blocks - 1) / blocks;
+  int refill_min = 16;
+  if (const char* ev = getenv("MK_FUSED_STREAM_REFILL")) refill_min = atoi(ev);   // tuning
   const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
   if (hipError_t e = allow_lds<fused_move_to_kernel<NC>>(lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(fused_move_to_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, goals, dt, damping, B,
-                     max_steps, max_iters, pos_tol, ori_tol, wp_pos_thr, wp_pos_step, wp_rot_thr, steps, reached,
-                     solves, status);
+                     chunk, refill_min, max_steps, max_iters, pos_tol, ori_tol, wp_pos_thr, wp_pos_step, wp_rot_thr,
+                     steps, reached, solves, status);
   return hipGetLastError();
 }
 
