@@ -121,6 +121,10 @@ typedef struct mk_problem_info {
   int32_t n_rows;        /* rows of the stacked inequality matrix G (mink/solve_ik.py:40) */
   int32_t fused;         /* 1: the single-kernel structured path serves this problem */
   int32_t n_chain;       /* dofs with dense coupling in the fused path */
+  int32_t staged;        /* 1: mk_solve_ik_batch runs the structured kernel on every problem and the
+                            general kernel only on those with a collision pair within its detection
+                            distance (one frame task, optionally a relative frame task on the same
+                            frame, posture tasks, any limits) */
 } mk_problem_info;
 
 /* Replaces mujoco.MjModel.from_xml_path + mujoco.MjData construction

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -19,6 +20,9 @@
 hipError_t mk_fused_launch_step(int nc, const MkFusedDesc* d_desc, int nq, const double* q, const double* targets,
                                 int target_stride, double dt, double damping, int B, double* v, int32_t* status,
                                 hipStream_t stream);
+hipError_t mk_fused_launch_step_ext(int nc, const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nq, const double* q,
+                                    const double* targets, int target_stride, double dt, double damping, int B,
+                                    double* v, int32_t* status, hipStream_t stream);
 hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, double* q, const double* targets,
                                    int target_stride, double dt, double damping, int B, int max_iters,
                                    double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
@@ -120,6 +124,9 @@ struct mk_problem {
   int nc_kernel;            // template size used by the fused kernels
   MkFusedDesc* d_fused;     // device copy
   MkFusedDesc h_fused;
+  bool staged;              // structured kernel first, general kernel for problems with a collision pair in range
+  MkFusedExt h_ext;
+  MkFusedExt* d_ext;
   bool dense;               // the dense (general) path can serve this problem
   std::string dense_why;    // why not, otherwise
   MkDenseProblem h_dense;
@@ -180,18 +187,69 @@ int frame_body_and_local(const HostModel& m, int frame_type, int frame_id, int* 
 
 const int kFusedSizes[] = {4, 6, 7, 8, 10, 12};
 
+// Brings 1-dof joint j to canonical form.  (ppos, pquat) is the fixed transform accumulated
+// since the previous joint; on return (pq, pp) is the fixed transform in front of the joint
+// (its qpos0 folded in) and (ppos, pquat) the one behind it.  A joint with unit axis a and
+// anchor p in its body frame is F Jz(q - qpos0) F^-1 with F = (translation p, rotation taking
+// z to a) and Jz the motion about / along z.
+bool canonical_joint(const HostModel& m, int j, double* ppos, double* pquat, double* pq, double* pp, std::string& why) {
+  const int jt = m.jnt_type[j];
+  double a[3] = {m.jnt_axis[3 * j], m.jnt_axis[3 * j + 1], m.jnt_axis[3 * j + 2]};
+  const double an = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+  if (!(an > MK_MINVAL)) { why = "zero joint axis"; return false; }
+  for (double& c : a) c /= an;
+  // F: shortest rotation taking z to a (half-turn about x when a = -z), anchored at the joint for hinges
+  double fq[4] = {1.0 + a[2], -a[1], a[0], 0.0};
+  if (1.0 + a[2] < 1e-12) { fq[0] = 0.0; fq[1] = 1.0; fq[2] = 0.0; }
+  hq_normalize(fq);
+  const double zero3[3] = {0, 0, 0};
+  const double* fp = (jt == MK_JNT_HINGE) ? &m.jnt_pos[3 * j] : zero3;
+  compose(ppos, pquat, fp, fq);
+  const double q0 = m.qpos0[m.jnt_qposadr[j]];
+  if (q0 != 0.0) {  // Jz(-qpos0)
+    const double zq[4] = {std::cos(-0.5 * q0), 0.0, 0.0, std::sin(-0.5 * q0)};
+    const double zp[3] = {0.0, 0.0, -q0};
+    const double id[4] = {1, 0, 0, 0};
+    if (jt == MK_JNT_HINGE) compose(ppos, pquat, zero3, zq); else compose(ppos, pquat, zp, id);
+  }
+  memcpy(pq, pquat, 4 * sizeof(double));
+  memcpy(pp, ppos, 3 * sizeof(double));
+  // behind the joint: F^-1 = (rotation conj(fq), translation -R(conj(fq)) fp)
+  const double fqi[4] = {fq[0], -fq[1], -fq[2], -fq[3]};
+  double r[3];
+  hq_rotate(fqi, fp, r);
+  ppos[0] = -r[0]; ppos[1] = -r[1]; ppos[2] = -r[2];
+  memcpy(pquat, fqi, sizeof(fqi));
+  return true;
+}
+
+struct BodyAnchor {   // body frame (after its joints) in the frame behind chain slot `slot` (-1: the world)
+  int slot;
+  double pos[3], quat[4];
+};
+
 // Tries to express the problem in the structured form the fused kernels solve.
 // Returns false (with `why`) when the generic dense path is needed instead.
+// With X given, one RelativeFrameTask on the frame task's frame and CollisionAvoidanceLimits
+// are accepted as well and described in X (see MkFusedExt); *needs_ext tells whether X is used.
 bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const mk_limit_desc* limits, int nlimit,
-                 MkFusedDesc& D, int* nc_kernel, std::string& why) {
+                 MkFusedDesc& D, int* nc_kernel, std::string& why, MkFusedExt* X = nullptr, bool* needs_ext = nullptr) {
   memset(&D, 0, sizeof(D));
+  if (X) memset(X, 0, sizeof(*X));
+  if (needs_ext) *needs_ext = false;
   if (m.nv > MK_MAX_NV || m.nq > MK_MAX_NQ) { why = "model too large"; return false; }
-  int frame_task = -1, nposture = 0, off = 0, target_off = 0;
+  int frame_task = -1, rel_task = -1, nposture = 0, off = 0, target_off = 0;
   for (int t = 0; t < ntask; ++t) {
     if (tasks[t].type == MK_TASK_FRAME) {
       if (frame_task >= 0) { why = "more than one frame task"; return false; }
       frame_task = t;
       target_off = off;
+      off += 7;
+    } else if (tasks[t].type == MK_TASK_RELATIVE_FRAME && X) {
+      if (rel_task >= 0) { why = "more than one relative frame task"; return false; }
+      rel_task = t;
+      X->has_rel = 1;
+      X->rel_target_off = off;
       off += 7;
     } else if (tasks[t].type == MK_TASK_POSTURE) {
       if (++nposture > MK_MAX_POSTURE) { why = "too many posture tasks"; return false; }
@@ -201,8 +259,13 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
     }
   }
   if (frame_task < 0) { why = "no frame task"; return false; }
+  bool any_collision = false;
   for (int l = 0; l < nlimit; ++l)
-    if (limits[l].type == MK_LIMIT_COLLISION) { why = "collision limit adds general rows"; return false; }
+    if (limits[l].type == MK_LIMIT_COLLISION) {
+      if (!X) { why = "collision limit adds general rows"; return false; }
+      any_collision = true;
+    }
+  if (needs_ext) *needs_ext = any_collision || rel_task >= 0;
   for (int j = 0; j < m.njnt; ++j)
     if (m.jnt_type[j] == MK_JNT_BALL) { why = "ball joint"; return false; }
 
@@ -240,6 +303,7 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
   // transform in front of the joint, F^-1 into the one behind it (`carry`).
   double ppos[3] = {0, 0, 0}, pquat[4] = {1, 0, 0, 0};   // fixed transform since the previous joint
   int nc = 0;
+  std::vector<BodyAnchor> anchor(m.nbody, BodyAnchor{-2, {0, 0, 0}, {1, 0, 0, 0}});   // -2: not on the path
   for (int b : path) {
     if (m.body_mocapid[b] >= 0) { why = "frame attached to a mocap body"; return false; }
     compose(ppos, pquat, &m.body_pos[3 * b], &m.body_quat[4 * b]);
@@ -248,41 +312,18 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
       const int jt = m.jnt_type[j];
       if (jt != MK_JNT_HINGE && jt != MK_JNT_SLIDE) { why = "free/ball joint on the task chain"; return false; }
       if (nc >= MK_MAX_CHAIN) { why = "task chain longer than the fused kernels support"; return false; }
-      double a[3] = {m.jnt_axis[3 * j], m.jnt_axis[3 * j + 1], m.jnt_axis[3 * j + 2]};
-      const double an = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
-      if (!(an > MK_MINVAL)) { why = "zero joint axis on the task chain"; return false; }
-      for (double& c : a) c /= an;
-      // F: shortest rotation taking z to a (half-turn about x when a = -z), anchored at j for hinges
-      double fq[4] = {1.0 + a[2], -a[1], a[0], 0.0};
-      if (1.0 + a[2] < 1e-12) { fq[0] = 0.0; fq[1] = 1.0; fq[2] = 0.0; }
-      hq_normalize(fq);
-      const double zero3[3] = {0, 0, 0};
-      const double* fp = (jt == MK_JNT_HINGE) ? &m.jnt_pos[3 * j] : zero3;
-      compose(ppos, pquat, fp, fq);
-      const int qadr = m.jnt_qposadr[j];
-      const double q0 = m.qpos0[qadr];
-      if (q0 != 0.0) {  // Jz(-qpos0)
-        const double zq[4] = {std::cos(-0.5 * q0), 0.0, 0.0, std::sin(-0.5 * q0)};
-        const double zp[3] = {0.0, 0.0, -q0};
-        const double id[4] = {1, 0, 0, 0};
-        if (jt == MK_JNT_HINGE) compose(ppos, pquat, zero3, zq); else compose(ppos, pquat, zp, id);
-      }
       MkSegC& sc = D.segc[nc];
-      memcpy(sc.pq, pquat, sizeof(pquat));
-      memcpy(sc.pp, ppos, sizeof(ppos));
+      if (!canonical_joint(m, j, ppos, pquat, sc.pq, sc.pp, why)) { why += " on the task chain"; return false; }
       sc.hinge = (jt == MK_JNT_HINGE) ? 1.0 : 0.0;
       sc.slide = 1.0 - sc.hinge;
-      D.seg_qadr[nc] = qadr;
+      D.seg_qadr[nc] = m.jnt_qposadr[j];
       D.seg_dof[nc] = m.jnt_dofadr[j];
       D.dof[m.jnt_dofadr[j]].slot = nc;
       ++nc;
-      // carry = F^-1: rotation conj(fq), translation -R(conj(fq)) fp
-      const double fqi[4] = {fq[0], -fq[1], -fq[2], -fq[3]};
-      double r[3];
-      hq_rotate(fqi, fp, r);
-      ppos[0] = -r[0]; ppos[1] = -r[1]; ppos[2] = -r[2];
-      memcpy(pquat, fqi, sizeof(fqi));
     }
+    anchor[b].slot = nc - 1;
+    memcpy(anchor[b].pos, ppos, sizeof(ppos));
+    memcpy(anchor[b].quat, pquat, sizeof(pquat));
   }
   if (nc == 0) { why = "task frame has no moving joints"; return false; }
   compose(ppos, pquat, lpos, lquat);
@@ -387,6 +428,129 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
   for (int i = 0; i < m.nv; ++i) {
     if (D.dof[i].slot >= 0 || D.dof[i].kind != MK_DOF_SCALAR) continue;
     if (!pack(i, D.ddof[D.nd++])) { why = "several configuration limits on one dof"; return false; }
+  }
+  if (!X) return true;
+
+  // ---- extension: relative frame term ----
+  if (rel_task >= 0) {
+    const mk_task_desc& rt = tasks[rel_task];
+    if (rt.frame_type != ft.frame_type || rt.frame_id != ft.frame_id) { why = "relative frame task on another frame than the frame task"; return false; }
+    if (rt.ncost != 6) { why = "frame task cost must have 6 entries"; return false; }
+    int rb;
+    double rpos[3], rquat[4];
+    if (frame_body_and_local(m, rt.root_type, rt.root_id, &rb, rpos, rquat) != MK_OK) { why = g_last_error; return false; }
+    // climb from the root's body through welded bodies to a body of the chain (or the world)
+    double xp[3] = {rpos[0], rpos[1], rpos[2]}, xq[4] = {rquat[0], rquat[1], rquat[2], rquat[3]};
+    int r = rb;
+    while (r != 0 && anchor[r].slot == -2) {
+      if (m.body_jntnum[r] > 0 || m.body_mocapid[r] >= 0) { why = "root frame of the relative task moves off the task chain"; return false; }
+      double np[3] = {m.body_pos[3 * r], m.body_pos[3 * r + 1], m.body_pos[3 * r + 2]};
+      double nq4[4] = {m.body_quat[4 * r], m.body_quat[4 * r + 1], m.body_quat[4 * r + 2], m.body_quat[4 * r + 3]};
+      compose(np, nq4, xp, xq);
+      memcpy(xp, np, sizeof(np));
+      memcpy(xq, nq4, sizeof(nq4));
+      r = m.body_parentid[r];
+    }
+    double bp[3] = {0, 0, 0}, bq[4] = {1, 0, 0, 0};
+    int slot = -1;
+    if (r != 0) {
+      slot = anchor[r].slot;
+      memcpy(bp, anchor[r].pos, sizeof(bp));
+      memcpy(bq, anchor[r].quat, sizeof(bq));
+    }
+    compose(bp, bq, xp, xq);
+    X->rel_slot = slot;
+    memcpy(X->rel_xp, bp, sizeof(bp));
+    memcpy(X->rel_xq, bq, sizeof(bq));
+    memcpy(X->rel_cost, rt.cost, 6 * sizeof(double));
+    X->rel_gain = rt.gain;
+    X->rel_lm = rt.lm_damping;
+  }
+
+  // ---- extension: collision screen ----
+  int tip = path.back();   // deepest body of the path: its anchor leads from the last chain slot
+  std::vector<int> body_slot(m.nbody, -1);
+  auto coll_body = [&](int gb) -> int {
+    if (body_slot[gb] >= 0) return body_slot[gb];
+    if (X->ncbody >= MK_MAX_CBODY) { why = "too many bodies with collision geoms"; return -1; }
+    MkCollBody CB;
+    memset(&CB, 0, sizeof(CB));
+    // bodies from gb upwards until the tip of the chain, a free-joint body or the world
+    std::vector<int> up;
+    int b = gb;
+    while (b != 0 && b != tip && !(m.body_jntnum[b] == 1 && m.jnt_type[m.body_jntadr[b]] == MK_JNT_FREE)) {
+      up.insert(up.begin(), b);
+      b = m.body_parentid[b];
+    }
+    double pp[3] = {0, 0, 0}, pq[4] = {1, 0, 0, 0};
+    if (b == tip && b != 0) {
+      CB.kind = MK_CB_TIP;
+      memcpy(pp, anchor[tip].pos, sizeof(pp));
+      memcpy(pq, anchor[tip].quat, sizeof(pq));
+      if (anchor[tip].slot != nc - 1) { why = "internal: tip anchor"; return -1; }
+    } else if (b == 0) {
+      CB.kind = MK_CB_WORLD;
+    } else {
+      CB.kind = MK_CB_FREE;
+      CB.free_qadr = m.jnt_qposadr[m.body_jntadr[b]];
+    }
+    for (int c : up) {
+      if (anchor[c].slot != -2) { why = "collision geom on an inner body of the task chain"; return -1; }
+      if (m.body_mocapid[c] >= 0) { why = "collision geom on a mocap body"; return -1; }
+      compose(pp, pq, &m.body_pos[3 * c], &m.body_quat[4 * c]);
+      for (int j = m.body_jntadr[c]; j < m.body_jntadr[c] + m.body_jntnum[c]; ++j) {
+        const int jt = m.jnt_type[j];
+        if (jt != MK_JNT_HINGE && jt != MK_JNT_SLIDE) { why = "free/ball joint below a collision body"; return -1; }
+        if (CB.kind == MK_CB_WORLD) { why = "collision geom on a separate articulated branch"; return -1; }
+        if (CB.nseg >= MK_MAX_CSEG) { why = "too many joints between the chain and a collision body"; return -1; }
+        MkCollSeg& S = CB.seg[CB.nseg++];
+        if (!canonical_joint(m, j, pp, pq, S.pq, S.pp, why)) return -1;
+        S.hinge = (jt == MK_JNT_HINGE) ? 1.0 : 0.0;
+        S.slide = 1.0 - S.hinge;
+        S.qadr = m.jnt_qposadr[j];
+      }
+    }
+    if (CB.kind == MK_CB_FREE && CB.nseg > 0) { why = "joints below a free body"; return -1; }
+    memcpy(CB.tp, pp, sizeof(pp));
+    memcpy(CB.tq, pq, sizeof(pq));
+    X->cbody[X->ncbody] = CB;
+    return body_slot[gb] = X->ncbody++;
+  };
+  std::vector<int> geom_slot(m.ngeom, -1);
+  auto coll_geom = [&](int g) -> int {
+    if (geom_slot[g] >= 0) return geom_slot[g];
+    if (X->ncgeom >= MK_MAX_CGEOM) { why = "too many collision geoms"; return -1; }
+    const int bs = coll_body(m.geom_bodyid[g]);
+    if (bs < 0) return -1;
+    MkCollGeom& G = X->cgeom[X->ncgeom];
+    G.body = bs;
+    G.type = m.geom_type[g];
+    memcpy(G.lp, &m.geom_pos[3 * g], 24);
+    memcpy(G.lq, &m.geom_quat[4 * g], 32);
+    memcpy(G.size, &m.geom_size[3 * g], 24);
+    const double* sz = G.size;
+    G.rbound = G.type == 2 ? sz[0] : G.type == 3 ? sz[0] + sz[1] : G.type == 6 ? std::sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]) : 0.0;
+    return geom_slot[g] = X->ncgeom++;
+  };
+  for (int l = 0; l < nlimit; ++l) {
+    const mk_limit_desc& L = limits[l];
+    if (L.type != MK_LIMIT_COLLISION) continue;
+    for (int k = 0; k < L.n; ++k) {
+      int g1 = L.index[2 * k], g2 = L.index[2 * k + 1];
+      if (g1 < 0 || g1 >= m.ngeom || g2 < 0 || g2 >= m.ngeom) { why = "geom id out of range"; return false; }
+      if (m.geom_type[g1] > m.geom_type[g2]) std::swap(g1, g2);
+      const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+      const bool ok = (t1 == 0 && (t2 == 2 || t2 == 3 || t2 == 6)) || (t1 == 2 && (t2 == 2 || t2 == 3 || t2 == 6)) ||
+                      (t1 == 3 && (t2 == 3 || t2 == 6)) || (t1 == 6 && t2 == 6);
+      if (!ok) { why = "geom pair types without a distance routine"; return false; }
+      if (X->ncpair >= MK_MAX_CPAIR) { why = "too many collision pairs"; return false; }
+      const int s1 = coll_geom(g1), s2 = coll_geom(g2);
+      if (s1 < 0 || s2 < 0) return false;
+      MkCollPair& P = X->cpair[X->ncpair++];
+      P.g1 = s1;
+      P.g2 = s2;
+      P.d_detect = L.collision_detection_distance;
+    }
   }
   return true;
 }
@@ -731,9 +895,24 @@ int mk_problem_create(const mk_model* model, const mk_task_desc* tasks, int32_t 
   p->info.n_rows = count_rows(m, limits, nlimit);
   std::string why;
   p->fused = build_fused(m, tasks, ntask, limits, nlimit, p->h_fused, &p->nc_kernel, why);
+  p->staged = false;
+  p->d_ext = nullptr;
+  if (!p->fused) {
+    // the same structured form plus a relative frame term and / or a collision screen?
+    std::string why2;
+    bool needs = false;
+    int nck = 0;
+    // (MK_NO_STAGED set: tests and timing of the general kernel alone)
+    if (!getenv("MK_NO_STAGED") &&
+        build_fused(m, tasks, ntask, limits, nlimit, p->h_fused, &nck, why2, &p->h_ext, &needs) && needs) {
+      p->staged = true;
+      p->nc_kernel = nck;
+    }
+  }
   p->info.fused = p->fused ? 1 : 0;
-  p->info.n_chain = p->fused ? p->h_fused.nc : 0;
-  if (p->fused) {
+  p->info.staged = p->staged ? 1 : 0;
+  p->info.n_chain = (p->fused || p->staged) ? p->h_fused.nc : 0;
+  if (p->fused || p->staged) {
     void* d = nullptr;
     if (hipMalloc(&d, sizeof(MkFusedDesc)) != hipSuccess ||
         hipMemcpy(d, &p->h_fused, sizeof(MkFusedDesc), hipMemcpyHostToDevice) != hipSuccess) {
@@ -743,6 +922,17 @@ int mk_problem_create(const mk_model* model, const mk_task_desc* tasks, int32_t 
     }
     p->d_fused = static_cast<MkFusedDesc*>(d);
     p->allocs.push_back(d);
+    if (p->staged) {
+      void* dx = nullptr;
+      if (hipMalloc(&dx, sizeof(MkFusedExt)) != hipSuccess ||
+          hipMemcpy(dx, &p->h_ext, sizeof(MkFusedExt), hipMemcpyHostToDevice) != hipSuccess) {
+        if (dx) (void)hipFree(dx);
+        mk_problem_destroy(p);
+        return fail(MK_ERR_HIP, "could not upload the problem descriptor");
+      }
+      p->d_ext = static_cast<MkFusedExt*>(dx);
+      p->allocs.push_back(dx);
+    }
   }
   p->dense = build_dense(m, tasks, ntask, limits, nlimit, p->h_dense, p->task_k, p->allocs, p->dense_why);
   if (p->dense) {
@@ -756,6 +946,7 @@ int mk_problem_create(const mk_model* model, const mk_task_desc* tasks, int32_t 
     p->d_dense = static_cast<MkDenseProblem*>(d);
     p->allocs.push_back(d);
   }
+  if (p->staged && !p->dense) p->staged = false, p->info.staged = 0;   // the second stage is the general kernel
   if (!p->fused && !p->dense) {
     std::string msg = "no kernel path serves this problem: fused: " + why + "; dense: " + p->dense_why;
     mk_problem_destroy(p);
@@ -785,6 +976,18 @@ int mk_solve_ik_batch(const mk_problem* p, const double* d_q, const double* d_ta
   MK_ON_DEVICE(p->model);
   if (!d_q || !d_v || !d_status) return fail(MK_ERR_INVALID, "null argument");
   if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
+  if (p->staged) {
+    // Structured kernel for every problem; it marks the ones with a collision pair within its
+    // detection distance, and only those go through the general kernel (which overwrites
+    // their velocity and status).
+    MK_HIP(mk_fused_launch_step_ext(p->nc_kernel, p->d_fused, p->d_ext, p->info.nq, d_q, d_targets, p->info.target_stride,
+                                    dt, damping, B, d_v, d_status, static_cast<hipStream_t>(stream)));
+    if (p->h_ext.ncpair > 0)
+      MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets,
+                             p->info.target_stride, dt, damping, B, nullptr, nullptr, nullptr, nullptr, d_v, d_status, -1,
+                             nullptr, nullptr, static_cast<hipStream_t>(stream), nullptr, false, true));
+    return MK_OK;
+  }
   if (!p->fused) {
     MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets, p->info.target_stride, dt,
                            damping, B, nullptr, nullptr, nullptr, nullptr, d_v, d_status, -1, nullptr, nullptr,

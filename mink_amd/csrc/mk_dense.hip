@@ -994,9 +994,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MK_DENSE_WPE
                                                    double damping, int B, double* __restrict__ P_out,
                                                    double* __restrict__ c_out, double* __restrict__ G_out,
                                                    double* __restrict__ h_out, double* __restrict__ v_out,
-                                                   int32_t* __restrict__ status_out, int eval_task,
+                                                   int32_t* status_out, int eval_task,
                                                    double* __restrict__ err_out, double* __restrict__ jac_out,
-                                                   const int32_t* __restrict__ skip_flags, int accumulate_status) {
+                                                   const int32_t* __restrict__ skip_flags, int accumulate_status,
+                                                   int only_pending) {
   extern __shared__ double lds_base[];
   const int lane = threadIdx.x;
   const int n = m.nv, mrows = n_rows, mg = n_general;
@@ -1006,6 +1007,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MK_DENSE_WPE
   for (long b = blockIdx.x; b < B; b += gridDim.x) {
     // the iterated loop marks the problems that have left it: they are not touched again
     if (skip_flags && (skip_flags[b] & MK_ITER_DONE_BIT)) continue;
+    // second stage of a staged solve: only the problems the structured kernel left pending
+    if (only_pending && !(status_out[b] & MK_STATUS_PENDING)) continue;
     // ---- inputs, kinematics ----
     bool bad_lane = false;
     for (int i = lane; i < m.nq; i += 64) {
@@ -1371,14 +1374,15 @@ static int dense_grid(int B, size_t lds) {
 hipError_t mk_dense_launch(const MkDevModel& m, const MkDenseProblem* d_problem, int n_rows, int n_general,
                            const double* q, const double* targets, int target_stride, double dt, double damping, int B,
                            double* P, double* c, double* G, double* h, double* v, int32_t* status, int eval_task,
-                           double* err, double* jac, hipStream_t s, const int32_t* skip_flags, bool accumulate_status) {
+                           double* err, double* jac, hipStream_t s, const int32_t* skip_flags, bool accumulate_status,
+                           bool only_pending) {
   const size_t lds = mk_dense_lds_bytes(m.nv, n_general, m.nq, target_stride, m.nbody, m.njnt, m.npath);
   if (lds == 0) return hipErrorInvalidValue;
   static MkLdsGrant grant;
   if (hipError_t e = mk_grant_lds(reinterpret_cast<const void*>(dense_kernel), lds, grant); e != hipSuccess) return e;
   hipLaunchKernelGGL(dense_kernel, dim3(dense_grid(B, lds)), dim3(64), lds, s, m, d_problem, n_rows, n_general, m.npath, q,
                      targets, target_stride, dt, damping, B, P, c, G, h, v, status, eval_task, err, jac, skip_flags,
-                     accumulate_status ? 1 : 0);
+                     accumulate_status ? 1 : 0, only_pending ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -87,6 +87,51 @@ struct MkFusedDesc {
   MkDofC ddof[MK_MAX_NV];              // scalar dofs outside the chain, increasing dof order
 };
 
+// ---- extension of the fused path: a second frame term and a collision prefilter ----
+// A RelativeFrameTask on the same task frame whose root frame lies on the chain (or in the
+// world) shares the chain pass: T_root,frame is the pose carried by the backward pass at
+// the root's slot, and its Jacobian is the frame Jacobian with the columns of the root's
+// ancestors set to zero.  CollisionAvoidanceLimit pairs are only screened here: a pair that
+// a conservative bound puts beyond its detection distance contributes no row
+// (mink/limits/collision_avoidance_limit.py:192-199), and a problem with a pair in range is
+// handed to the general kernel.
+constexpr int MK_MAX_CBODY = 6;    // bodies carrying collision geoms
+constexpr int MK_MAX_CSEG = 4;     // 1-dof joints between the chain's last body and such a body
+constexpr int MK_MAX_CGEOM = 12;
+constexpr int MK_MAX_CPAIR = 16;
+enum { MK_CB_WORLD = 0, MK_CB_TIP = 1, MK_CB_FREE = 2 };
+constexpr int32_t MK_STATUS_PENDING = 1 << 30;   // in a status entry: the general kernel still has to solve it
+
+struct MkCollSeg {        // like MkSegC: fixed transform, then motion about / along z
+  double pq[4], pp[3];
+  double hinge, slide;
+  int32_t qadr, pad;
+};
+struct MkCollBody {
+  int32_t kind, nseg, free_qadr, pad;
+  MkCollSeg seg[MK_MAX_CSEG];
+  double tq[4], tp[3];    // fixed transform behind the last joint (WORLD: the world pose)
+  double pad2;
+};
+struct MkCollGeom {
+  int32_t body, type;     // index into cbody, MuJoCo geom type
+  double lq[4], lp[3];    // pose in the body frame
+  double size[3], rbound; // rbound: radius of a bounding sphere about the geom centre
+};
+struct MkCollPair {
+  int32_t g1, g2;         // indices into cgeom, ordered by geom type
+  double d_detect;
+};
+struct MkFusedExt {
+  int32_t has_rel, rel_slot, rel_target_off, ncbody;
+  int32_t ncgeom, ncpair, pad0, pad1;
+  double rel_cost[6], rel_gain, rel_lm;
+  double rel_xq[4], rel_xp[3], pad2;   // root frame in the frame the pass carries at rel_slot
+  MkCollBody cbody[MK_MAX_CBODY];
+  MkCollGeom cgeom[MK_MAX_CGEOM];
+  MkCollPair cpair[MK_MAX_CPAIR];
+};
+
 // ------------------------------------------------------------------ math ----
 // Reciprocal / reciprocal square root for normal-range positive-scale arguments:
 // hardware seed (v_rcp_f64 / v_rsq_f64) plus two Newton steps, ~1 ulp, without the

@@ -306,15 +306,19 @@ struct ChainJac {
 // frame (mink/configuration.py:143-153) without world-frame anchors / axes as
 // intermediates.  Hinges, slides and padding slots share one instruction stream (the
 // `hinge` factor of the slot selects), so the pass is straight-line code.
-template <int NC>
+template <int NC, bool CAP = false>
 MK_DEV void chain_jac_pose(const MkFusedDesc* __restrict__ D, const double (&qc)[NC], ChainJac<NC>& cj, Q4& Q, V3& t,
-                           M3& R) {
+                           M3& R, int cap_slot = 0, Q4* Qcap = nullptr, V3* tcap = nullptr) {
   Q = Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]};
   t = v3(D->post_pos[0], D->post_pos[1], D->post_pos[2]);
   R = q2m(Q);
   MkSegC s = D->segc[NC - 1];
 #pragma unroll
   for (int k = NC - 1; k >= 0; --k) {
+    if (CAP && k == cap_slot) {   // pose of the task frame in the frame behind joint cap_slot (wave-uniform)
+      *Qcap = Q;
+      *tcap = t;
+    }
     const MkSegC nx = D->segc[k > 0 ? k - 1 : 0];   // requested one slot ahead
     const double h = s.hinge;
     const double th = h * qc[k];       // hinge angle (0 for a slide)
@@ -345,6 +349,10 @@ MK_DEV void chain_jac_pose(const MkFusedDesc* __restrict__ D, const double (&qc)
     s = nx;
   }
   // (Q, t, R) is now the pose of the task frame in the world
+  if (CAP && cap_slot < 0) {
+    *Qcap = Q;
+    *tcap = t;
+  }
 }
 
 // Frame-task error e = log(T_wb^-1 T_wt) (mink/tasks/frame_task.py:95-122) of the frame at
@@ -418,11 +426,54 @@ MK_DEV bool rest_nonfinite(const MkFusedDesc* __restrict__ D, const double* row)
 //   INTEGRATE == false: row[dof] <- v[dof] for every non-chain dof (q is consumed)
 //   INTEGRATE == true : row[qadr] <- q (+) dt v for every non-chain dof, and their
 //                       velocity goes to vrow[dof] when vrow is not null
-template <int NC, bool INTEGRATE>
+template <int NC, bool INTEGRATE, bool REL = false>
 MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const double (&qc)[NC],
                          ChainJac<NC>& cj, double dt, double inv_dt, double damping, double (&x)[NC],
                          double* vrow, uint32_t& act, uint32_t& upper, bool warm, double* hstore,
-                         int hstride, bool input_bad = false) {
+                         int hstride, bool input_bad = false, const MkFusedExt* __restrict__ X = nullptr,
+                         Twist e_rel = Twist{V3{0, 0, 0}, V3{0, 0, 0}}) {
+  // second frame term (RelativeFrameTask, mink/tasks/relative_frame_task.py:106-142): its block of
+  // H goes to the lane's LDS column first, its share of c and of the diagonal to registers
+  double c_rel[NC], diag_rel = 0.0;
+  if (REL) {
+    M3 Jir, Bmr;
+    se3_ljacinv_blocks(Twist{neg(e_rel.v), neg(e_rel.w)}, Jir, Bmr);   // jlog(T_rt^-1 T_rf) = ljacinv(-e)
+    double rc[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) rc[r] = X->rel_cost[r];
+    const int rs = X->rel_slot;
+    double Jr[6][NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const double m = (k > rs) ? 1.0 : 0.0;   // joints in front of the root move root and frame alike
+      const V3 bl = v3(cj.J[0][k], cj.J[1][k], cj.J[2][k]);
+      const V3 ba = v3(cj.J[3][k], cj.J[4][k], cj.J[5][k]);
+      const V3 tl = mul(Jir, bl) + mul(Bmr, ba);
+      const V3 ta = mul(Jir, ba);
+      Jr[0][k] = m * rc[0] * tl.x; Jr[1][k] = m * rc[1] * tl.y; Jr[2][k] = m * rc[2] * tl.z;
+      Jr[3][k] = m * rc[3] * ta.x; Jr[4][k] = m * rc[4] * ta.y; Jr[5][k] = m * rc[5] * ta.z;
+    }
+    const double gr = X->rel_gain;
+    const double ewr[6] = {rc[0] * (-gr * e_rel.v.x), rc[1] * (-gr * e_rel.v.y), rc[2] * (-gr * e_rel.v.z),
+                           rc[3] * (-gr * e_rel.w.x), rc[4] * (-gr * e_rel.w.y), rc[5] * (-gr * e_rel.w.z)};
+    diag_rel = X->rel_lm * (ewr[0] * ewr[0] + ewr[1] * ewr[1] + ewr[2] * ewr[2] + ewr[3] * ewr[3] + ewr[4] * ewr[4] +
+                            ewr[5] * ewr[5]);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        double sr = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) sr += Jr[r][i] * Jr[r][j];
+        hstore[tri(i, j) * hstride] = sr;
+      }
+      double sr = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) sr += ewr[r] * Jr[r][i];
+      c_rel[i] = -sr;
+    }
+    asm volatile("" ::: "memory");
+  }
   const Twist e = cj.e;
   M3 Ji, Bm;
   se3_ljacinv_blocks(e, Ji, Bm);
@@ -445,6 +496,7 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
                   cost[3] * (-g * e.w.x), cost[4] * (-g * e.w.y), cost[5] * (-g * e.w.z)};
   double diag = damping + D->lm * (ew[0] * ew[0] + ew[1] * ew[1] + ew[2] * ew[2] + ew[3] * ew[3] +
                                    ew[4] * ew[4] + ew[5] * ew[5]);
+  if (REL) diag += diag_rel;
   // Levenberg-Marquardt terms of posture tasks need the error over every dof (rare).
   if (D->any_posture_lm) {
     for (int t = 0; t < D->nposture; ++t) {
@@ -477,6 +529,7 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
 #pragma unroll
       for (int r = 0; r < 6; ++r) s += Jw[r][i] * Jw[r][j];
       if (j == i) s += diag + dc.W;
+      if (REL) s += hstore[tri(i, j) * hstride];
       // straight to the lane's LDS column: the solver re-reads H from there, and the
       // registers are needed for the factor
 #if defined(MK_ABLATE) && MK_ABLATE == 2
@@ -489,6 +542,7 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
 #pragma unroll
     for (int r = 0; r < 6; ++r) s += ew[r] * Jw[r][i];
     c[i] = dc.B * qc[i] - dc.A - s;
+    if (REL) c[i] += c_rel[i];
     const double vb = dt * dc.vmax;
     hi[i] = fmin(dc.gain * (dc.upper - qc[i]), vb);
     lo[i] = fmax(-(dc.gain * (qc[i] - dc.lower)), -vb);
@@ -615,6 +669,179 @@ __global__ MK_KERNEL_ATTR void fused_step_kernel(const MkFusedDesc* __restrict__
   for (int k = 0; k < NC; ++k)
     if (D->seg_dof[k] >= 0) row[D->seg_dof[k]] = x[k] * inv_dt;
   if (valid) status_out[pb] = status;
+  __syncthreads();
+  tile_copy<false>(tile, stride, v_out + base * nv, rows, nv);
+}
+
+// Pose composition helpers of the collision screen.
+struct PoseQT {
+  Q4 q;
+  V3 t;
+};
+MK_DEV PoseQT pose_then(PoseQT a, Q4 bq, V3 bt) { return PoseQT{qmul(a.q, bq), a.t + qrot(a.q, bt)}; }
+
+// True when some CollisionAvoidanceLimit pair of the problem may be within its detection
+// distance: conservative lower bounds of the pair distances (bounding spheres; the support
+// extent of a box against a plane; the separating-axis gaps of two boxes) -- the same bounds
+// behind which the general kernel skips a pair, so a problem that passes has no finite
+// collision row there either.  (Qw, tw) is the world pose of the task frame, `row` the
+// lane's q.
+MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const double* row,
+                               Q4 Qw, V3 tw) {
+  // frame behind the chain's last joint: task frame o post^-1
+  const Q4 postq = Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]};
+  PoseQT tip;
+  tip.q = qmul(Qw, qconj(postq));
+  tip.t = tw - qrot(tip.q, v3(D->post_pos[0], D->post_pos[1], D->post_pos[2]));
+  PoseQT gp[MK_MAX_CGEOM];
+  const int nb = X->ncbody, ng = X->ncgeom;
+  for (int b = 0; b < nb; ++b) {
+    const MkCollBody& CB = X->cbody[b];
+    PoseQT p = PoseQT{Q4{1, 0, 0, 0}, v3(0, 0, 0)};
+    if (CB.kind == MK_CB_TIP) {
+      p = tip;
+      for (int sidx = 0; sidx < CB.nseg; ++sidx) {
+        const MkCollSeg& S = CB.seg[sidx];
+        p = pose_then(p, Q4{S.pq[0], S.pq[1], S.pq[2], S.pq[3]}, v3(S.pp[0], S.pp[1], S.pp[2]));
+        const double qv = row[S.qadr];
+        double sn, cs;
+        mk_sincos(0.5 * (S.hinge * qv), &sn, &cs);
+        p = pose_then(p, Q4{cs, 0.0, 0.0, sn}, v3(0.0, 0.0, S.slide * qv));
+      }
+    } else if (CB.kind == MK_CB_FREE) {
+      const double* f = row + CB.free_qadr;
+      p.t = v3(f[0], f[1], f[2]);
+      p.q = qnormalize(Q4{f[3], f[4], f[5], f[6]});
+    }
+    p = pose_then(p, Q4{CB.tq[0], CB.tq[1], CB.tq[2], CB.tq[3]}, v3(CB.tp[0], CB.tp[1], CB.tp[2]));
+#pragma unroll
+    for (int g = 0; g < MK_MAX_CGEOM; ++g) {
+      if (g < ng && X->cgeom[g].body == b) {
+        const MkCollGeom& G = X->cgeom[g];
+        gp[g] = pose_then(p, Q4{G.lq[0], G.lq[1], G.lq[2], G.lq[3]}, v3(G.lp[0], G.lp[1], G.lp[2]));
+      }
+    }
+  }
+  bool near = false;
+  const int np = X->ncpair;
+  for (int k = 0; k < np; ++k) {
+    const MkCollPair P = X->cpair[k];
+    PoseQT a = gp[0], b = gp[0];
+#pragma unroll
+    for (int g = 0; g < MK_MAX_CGEOM; ++g) {   // register arrays: select, do not index
+      if (g == P.g1) a = gp[g];
+      if (g == P.g2) b = gp[g];
+    }
+    const MkCollGeom& G1 = X->cgeom[P.g1];
+    const MkCollGeom& G2 = X->cgeom[P.g2];
+    double lower;
+    if (G1.type == 0) {   // plane: height of the other geom's centre minus its extent along the normal
+      const M3 R1 = q2m(a.q);
+      const V3 n = v3(R1.m[2], R1.m[5], R1.m[8]);
+      double ext = G2.rbound;
+      if (G2.type == 6) {
+        const M3 R2 = q2m(b.q);
+        const V3 nl = mulT(R2, n);
+        ext = fabs(nl.x) * G2.size[0] + fabs(nl.y) * G2.size[1] + fabs(nl.z) * G2.size[2];
+      }
+      lower = dot(b.t - a.t, n) - ext;
+    } else {
+      const V3 d = b.t - a.t;
+      lower = sqrt(dot(d, d)) - G1.rbound - G2.rbound;
+      if (G1.type == 6 && G2.type == 6 && lower < P.d_detect) {
+        // two boxes: the largest gap along the 15 candidate separating axes
+        const M3 R1 = q2m(a.q), R2 = q2m(b.q);
+        const V3 h1 = v3(G1.size[0], G1.size[1], G1.size[2]), h2 = v3(G2.size[0], G2.size[1], G2.size[2]);
+        double gap = -INFINITY;
+#pragma unroll
+        for (int ax = 0; ax < 15; ++ax) {
+          V3 u;
+          if (ax < 3) u = v3(R1.m[ax], R1.m[3 + ax], R1.m[6 + ax]);
+          else if (ax < 6) u = v3(R2.m[ax - 3], R2.m[ax], R2.m[ax + 3]);
+          else {
+            const int i = (ax - 6) / 3, j = (ax - 6) % 3;
+            u = cross(v3(R1.m[i], R1.m[3 + i], R1.m[6 + i]), v3(R2.m[j], R2.m[3 + j], R2.m[6 + j]));
+          }
+          const double n2 = dot(u, u);
+          if (n2 >= 1e-12) {
+            u = (1.0 / sqrt(n2)) * u;
+            const V3 a1 = mulT(R1, u), a2 = mulT(R2, u);
+            const double ra = fabs(a1.x) * h1.x + fabs(a1.y) * h1.y + fabs(a1.z) * h1.z;
+            const double rb = fabs(a2.x) * h2.x + fabs(a2.y) * h2.y + fabs(a2.z) * h2.z;
+            gap = fmax(gap, fabs(dot(d, u)) - ra - rb);
+          }
+        }
+        lower = fmax(lower, gap);
+      }
+    }
+    near |= !(lower >= P.d_detect);   // also true for a non-finite bound
+  }
+  return near;
+}
+
+// fused_step_kernel with the extension descriptor: an optional RelativeFrameTask term and the
+// collision screen.  A problem with a collision pair in range gets MK_STATUS_PENDING in its
+// status entry (its velocity row is then provisional) and is solved by the general kernel.
+template <int NC>
+__global__ MK_KERNEL_ATTR void fused_step_ext_kernel(const MkFusedDesc* __restrict__ D,
+                                                     const MkFusedExt* __restrict__ X,
+                                                     const double* __restrict__ q,
+                                                     const double* __restrict__ targets, int target_stride,
+                                                     double dt, double damping, int B,
+                                                     double* __restrict__ v_out, int32_t* __restrict__ status_out) {
+  extern __shared__ double tile[];
+  const int nq = D->nq, nv = D->nv;
+  const int stride = nq | 1;
+  const double inv_dt = 1.0 / dt;
+  const int lane = threadIdx.x;
+  const long base = (long)blockIdx.x * 64;
+  const int rows = (int)min((long)64, (long)B - base);
+  tile_copy<true>(tile, stride, const_cast<double*>(q) + base * nq, rows, nq);
+  __syncthreads();
+  const bool valid = lane < rows;
+  double* row = tile + lane * stride;
+  double* hlds = tile + 64 * stride + lane;
+  if (!valid) {
+    for (int i = 0; i < nq; ++i) row[i] = tile[i];
+  }
+  const long pb = valid ? base + lane : base;
+  const double* tg = targets + pb * target_stride + D->target_off;
+  const Q4 Qt = Q4{tg[0], tg[1], tg[2], tg[3]};
+  const V3 pt = v3(tg[4], tg[5], tg[6]);
+  double qc[NC], x[NC];
+  load_chain_q<NC>(D, row, qc);
+  ChainJac<NC> cj;
+  Q4 Qw, Qcap = Q4{1, 0, 0, 0};
+  V3 tw, tcap = v3(0, 0, 0);
+  M3 Rw;
+  chain_jac_pose<NC, true>(D, qc, cj, Qw, tw, Rw, X->has_rel ? X->rel_slot : NC, &Qcap, &tcap);
+  cj.e = frame_error(Qw, tw, Rw, Qt, pt);
+  bool bad = rest_nonfinite(D, row);
+  // collision screen first: it reads the lane's q, which the solve consumes
+  const bool pending = X->ncpair > 0 && collision_in_range(D, X, row, Qw, tw);
+  uint32_t act = 0u, upper = 0u;
+  int status;
+  if (X->has_rel) {
+    // T_root,frame = X^-1 o (pose carried at the root's slot); e = log(T_rt^-1 T_rf)
+    const double* tr = targets + pb * target_stride + X->rel_target_off;
+    const Q4 Qrt = Q4{tr[0], tr[1], tr[2], tr[3]};
+    const V3 prt = v3(tr[4], tr[5], tr[6]);
+    bad |= !(fabs(tr[0] + tr[1] + tr[2] + tr[3] + tr[4] + tr[5] + tr[6]) < INFINITY);
+    const Q4 xqi = qconj(Q4{X->rel_xq[0], X->rel_xq[1], X->rel_xq[2], X->rel_xq[3]});
+    const Q4 Qrf = qmul(xqi, Qcap);
+    const V3 trf = qrot(xqi, tcap - v3(X->rel_xp[0], X->rel_xp[1], X->rel_xp[2]));
+    const M3 Rt = q2m(Qrt);
+    const Twist e_rel = se3_log(qmul(qconj(Qrt), Qrf), mulT(Rt, trf - prt));
+    status = solve_problem<NC, false, true>(D, row, qc, cj, dt, inv_dt, damping, x, nullptr, act, upper, false, hlds, 64,
+                                            bad, X, e_rel);
+  } else {
+    status = solve_problem<NC, false, false>(D, row, qc, cj, dt, inv_dt, damping, x, nullptr, act, upper, false, hlds, 64,
+                                             bad);
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k)
+    if (D->seg_dof[k] >= 0) row[D->seg_dof[k]] = x[k] * inv_dt;
+  if (valid) status_out[pb] = (pending && status != 3) ? MK_STATUS_PENDING : status;
   __syncthreads();
   tile_copy<false>(tile, stride, v_out + base * nv, rows, nv);
 }
@@ -1064,6 +1291,30 @@ hipError_t mk_fused_launch_step(int nc, const MkFusedDesc* d_desc, int nq, const
   switch (nc) {
 #define MK_CASE(N) \
   case N: return launch_step<N>(d_desc, nq, q, targets, target_stride, dt, damping, B, v, status, stream);
+    MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
+#undef MK_CASE
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <int NC>
+static hipError_t launch_step_ext(const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nq, const double* q,
+                                  const double* targets, int target_stride, double dt, double damping, int B, double* v,
+                                  int32_t* status, hipStream_t stream) {
+  const int blocks = (B + 63) / 64;
+  const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
+  if (hipError_t e = allow_lds<fused_step_ext_kernel<NC>>(lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(fused_step_ext_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, d_ext, q, targets,
+                     target_stride, dt, damping, B, v, status);
+  return hipGetLastError();
+}
+
+hipError_t mk_fused_launch_step_ext(int nc, const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nq, const double* q,
+                                    const double* targets, int target_stride, double dt, double damping, int B,
+                                    double* v, int32_t* status, hipStream_t stream) {
+  switch (nc) {
+#define MK_CASE(N) \
+  case N: return launch_step_ext<N>(d_desc, d_ext, nq, q, targets, target_stride, dt, damping, B, v, status, stream);
     MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
 #undef MK_CASE
     default: return hipErrorInvalidValue;

@@ -130,7 +130,7 @@ hipError_t mk_dense_launch(const MkDevModel& m, const MkDenseProblem* d_problem,
                            const double* q, const double* targets, int target_stride, double dt, double damping, int B,
                            double* P, double* c, double* G, double* h, double* v, int32_t* status, int eval_task,
                            double* err, double* jac, hipStream_t s, const int32_t* skip_flags = nullptr,
-                           bool accumulate_status = false);
+                           bool accumulate_status = false, bool only_pending = false);
 // Solves caller-provided dense QPs.
 hipError_t mk_dense_qp_launch(const double* P, const double* c, const double* G, const double* h, int n, int m, int B,
                               double* x, int32_t* status, hipStream_t s);

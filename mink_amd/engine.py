@@ -104,6 +104,7 @@ class DeviceProblem:
         self.n_rows = info.n_rows
         self.fused = bool(info.fused)
         self.n_chain = info.n_chain
+        self.staged = bool(info.staged)
 
     def __del__(self):
         h = getattr(self, "handle", None)

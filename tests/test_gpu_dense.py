@@ -182,3 +182,73 @@ def test_collision_rows_and_config4_solve(env, golden_dir):
     v, st = prob4.solve(dev(q), dev(targets), W.DT, W.DAMPING)
     assert int(st.abs().sum()) == 0
     np.testing.assert_allclose(v.cpu().numpy(), np.array(ref_v), rtol=0, atol=1e-8)
+
+
+def test_staged_solve_matches_general_kernel(env):
+    """Config-4 problems (Frame + RelativeFrame + Posture, Cfg + Vel + Collision) through the
+    staged solve -- structured lane-per-problem kernel for every problem, general kernel only
+    for those with a collision pair within its detection distance -- against the general
+    kernel alone on every problem."""
+    from mink_amd.engine import DeviceProblem
+    model, dm = env
+    tasks, limits = W.config4_specs(model)
+    B = 8192
+    q, tg = W.config4_inputs(model, dm, B, 5)
+    staged = DeviceProblem(dm, tasks, limits)
+    assert staged.staged and not staged.fused and staged.n_chain == 10
+    os.environ["MK_NO_STAGED"] = "1"
+    try:
+        general = DeviceProblem(dm, tasks, limits)
+    finally:
+        del os.environ["MK_NO_STAGED"]
+    assert not general.staged
+    v_s, st_s = staged.solve(q, tg, W.DT, W.DAMPING)
+    v_g, st_g = general.solve(q, tg, W.DT, W.DAMPING)
+    assert int(st_s.abs().sum()) == 0 and int(st_g.abs().sum()) == 0
+    d = (v_s - v_g).abs().max(dim=1).values
+    print("staged vs general: max |dv| =", float(d.max()))
+    assert float(d.max()) <= 1e-9
+    # how many problems the second stage had to take: those with a finite collision row
+    P, c, G, h = general.build_qp(q, tg, W.DT, W.DAMPING)
+    finite = torch.isfinite(h[:, -8:]).any(dim=1)
+    print("problems with a collision row in range:", float(finite.double().mean()))
+    assert 0.02 < float(finite.double().mean()) < 0.3
+    # a row of non-finite input: status 3 on both paths, neighbours untouched
+    qb = q[:64].clone()
+    qb[3, 5] = float("nan")
+    v_b, st_b = staged.solve(qb, tg[:64].contiguous(), W.DT, W.DAMPING)
+    assert st_b.cpu().tolist() == [0, 0, 0, 3] + [0] * 60 and float(v_b[3].abs().max()) == 0.0
+    assert torch.equal(v_b[4:], v_s[4:64])
+
+
+def test_staged_relative_frame_without_collision(env):
+    """Frame + RelativeFrame (root: base_link body, world body, a site) + Posture with box limits
+    only: the structured kernel alone (no second stage) against the general kernel."""
+    from mink_amd.engine import DeviceProblem
+    model, dm = env
+    rng = np.random.default_rng(9)
+    B = 2048
+    q = dev(W.sample_q(model, rng, B))
+    base = W.task_specs(model, False)
+    for root_type, root_id, cost, gain, lm in ((0, model.body_id("base_link"), [1.0, 2.0, 0.5, 0.7, 0.7, 0.7], 0.8, 0.5),
+                                               (0, 0, np.ones(6), 1.0, 0.0),
+                                               (0, model.body_id("bracelet_link"), np.ones(6), 1.0, 1.0),
+                                               (0, model.body_id("forearm_link"), np.ones(6), 0.5, 0.0)):
+        rel = dict(type=L.TASK_RELATIVE_FRAME, frame_type=2, frame_id=model.site_id("pinch_site"), root_type=root_type,
+                   root_id=root_id, cost=cost, gain=gain, lm_damping=lm)
+        tasks = [base[0], rel, base[1]]
+        staged = DeviceProblem(dm, tasks, W.limit_specs(model, True))
+        assert staged.staged
+        os.environ["MK_NO_STAGED"] = "1"
+        try:
+            general = DeviceProblem(dm, tasks, W.limit_specs(model, True))
+        finally:
+            del os.environ["MK_NO_STAGED"]
+        tq = dev(W.sample_q(model, rng, B))
+        t_world = dm.frame_pose(tq, 2, model.site_id("pinch_site"))
+        t_rel = dm.frame_pose(dev(W.sample_q(model, rng, B)), 2, model.site_id("pinch_site"))
+        tg = torch.cat([t_world, t_rel], dim=1).contiguous()
+        v_s, st_s = staged.solve(q, tg, W.DT, W.DAMPING)
+        v_g, st_g = general.solve(q, tg, W.DT, W.DAMPING)
+        assert int(st_s.abs().sum()) == 0 and int(st_g.abs().sum()) == 0
+        assert float((v_s - v_g).abs().max()) <= 1e-9, (root_id, float((v_s - v_g).abs().max()))
