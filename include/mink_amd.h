@@ -82,6 +82,15 @@ typedef struct mk_model_desc {
   const double* geom_size;      /* [ngeom*3] */
   const double* geom_pos;       /* [ngeom*3] */
   const double* geom_quat;      /* [ngeom*4] */
+  /* convex hulls of the meshes of mesh geoms (may all be 0 / NULL for a model without
+   * meshes): vertices in the frame of the geom, as mj_geomDistance sees them */
+  int32_t nmesh, nmeshvert;
+  const int32_t* geom_dataid;   /* [ngeom] mesh id of a mesh geom, else -1 */
+  const int32_t* mesh_vertadr;  /* [nmesh] */
+  const int32_t* mesh_vertnum;  /* [nmesh] */
+  const double* mesh_vert;      /* [nmeshvert*3] */
+  const double* mesh_center;    /* [nmesh*3] centre of a bounding sphere of the hull */
+  const double* mesh_radius;    /* [nmesh] */
 } mk_model_desc;
 
 /* One kinematic task.  Pose targets of frame tasks are per-problem inputs of the

@@ -39,6 +39,9 @@ class ModelDesc(C.Structure):
         ("site_bodyid", _pi32), ("site_pos", _pf64), ("site_quat", _pf64),
         ("geom_bodyid", _pi32), ("geom_type", _pi32), ("geom_size", _pf64), ("geom_pos", _pf64),
         ("geom_quat", _pf64),
+        ("nmesh", C.c_int32), ("nmeshvert", C.c_int32),
+        ("geom_dataid", _pi32), ("mesh_vertadr", _pi32), ("mesh_vertnum", _pi32),
+        ("mesh_vert", _pf64), ("mesh_center", _pf64), ("mesh_radius", _pf64),
     ]
 
 
@@ -87,9 +90,15 @@ def pack_model(model) -> Tuple[ModelDesc, list]:
     d = ModelDesc()
     for name in ("nq", "nv", "nbody", "njnt", "ngeom", "nsite"):
         setattr(d, name, int(getattr(model, name)))
-    for name, _ in ModelDesc._fields_[6:]:
-        ctype = dict(ModelDesc._fields_)[name]
-        arr = getattr(model, name)
+    d.nmesh = int(getattr(model, "nmesh", 0) or 0)
+    mv = getattr(model, "mesh_vert", None)
+    d.nmeshvert = 0 if mv is None else int(np.asarray(mv).reshape(-1, 3).shape[0])
+    for name, ctype in ModelDesc._fields_[6:]:
+        if ctype not in (_pi32, _pf64):
+            continue
+        arr = getattr(model, name, None)
+        if arr is None:
+            arr = np.full(model.ngeom, -1, dtype=np.int32) if name == "geom_dataid" else np.zeros(0)
         if name == "jnt_limited":
             arr = np.asarray(arr).astype(np.int32)
         arr = _i32(arr) if ctype is _pi32 else _f64(arr)

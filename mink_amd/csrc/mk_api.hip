@@ -73,6 +73,9 @@ struct HostModel {
   std::vector<double> site_pos, site_quat;
   std::vector<int32_t> geom_bodyid, geom_type;
   std::vector<double> geom_size, geom_pos, geom_quat;
+  int nmesh, nmeshvert;
+  std::vector<int32_t> geom_dataid, mesh_vertadr, mesh_vertnum;
+  std::vector<double> mesh_vert, mesh_center, mesh_radius;
 };
 
 void hq_mul(const double* a, const double* b, double* r) {
@@ -183,6 +186,26 @@ int frame_body_and_local(const HostModel& m, int frame_type, int frame_id, int* 
     return fail(MK_ERR_INVALID, "unknown frame type %d", frame_type);
   }
   return MK_OK;
+}
+
+// Can the kernels compute the distance of geoms g1, g2?  Closed forms exist for plane / sphere /
+// capsule / box pairs (except plane - plane); every other pair of convex geoms (ellipsoid,
+// cylinder, mesh with a hull, and those against the primitives) goes by support mappings.
+// MuJoCo geom types: plane 0, hfield 1, sphere 2, capsule 3, ellipsoid 4, cylinder 5, box 6, mesh 7.
+bool pair_supported(const HostModel& m, int g1, int g2, bool* convex, std::string& why) {
+  int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+  if (t1 > t2) { std::swap(t1, t2); std::swap(g1, g2); }
+  auto usable = [&](int g) {
+    const int t = m.geom_type[g];
+    if (t == 0 || (t >= 2 && t <= 6)) return true;
+    return t == 7 && m.geom_dataid[g] >= 0 && m.mesh_vertnum[m.geom_dataid[g]] > 0;
+  };
+  if (!usable(g1) || !usable(g2)) { why = "geom without a distance routine (height field, or a mesh without hull vertices in the model)"; return false; }
+  if (t1 == 0 && t2 == 0) { why = "plane - plane pair"; return false; }
+  const bool closed = (t1 == 0 && (t2 == 2 || t2 == 3 || t2 == 6)) || (t1 == 2 && (t2 == 2 || t2 == 3 || t2 == 6)) ||
+                      (t1 == 3 && (t2 == 3 || t2 == 6)) || (t1 == 6 && t2 == 6);
+  if (convex) *convex = !closed;
+  return true;
 }
 
 const int kFusedSizes[] = {4, 6, 7, 8, 10, 12};
@@ -633,12 +656,8 @@ bool build_dense(const HostModel& m, const mk_task_desc* tasks, int ntask, const
       for (int k = 0; k < L.n; ++k) {
         const int g1 = idx[2 * k], g2 = idx[2 * k + 1];
         if (g1 < 0 || g1 >= m.ngeom || g2 < 0 || g2 >= m.ngeom) { why = "geom id out of range"; return false; }
-        int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
-        if (t1 > t2) std::swap(t1, t2);
-        // MuJoCo geom types: plane 0, sphere 2, capsule 3, box 6
-        const bool ok = (t1 == 0 && (t2 == 2 || t2 == 3 || t2 == 6)) || (t1 == 2 && (t2 == 2 || t2 == 3 || t2 == 6)) ||
-                        (t1 == 3 && (t2 == 3 || t2 == 6)) || (t1 == 6 && t2 == 6);
-        if (!ok) { why = "geom pair types without a distance routine (supported: plane-{sphere,capsule,box}, sphere-{sphere,capsule,box}, capsule-{capsule,box}, box-box)"; return false; }
+        std::string why_pair;
+        if (!pair_supported(m, g1, g2, nullptr, why_pair)) { why = why_pair; return false; }
       }
       O.n = L.n;
       O.gain = L.gain;
@@ -703,6 +722,40 @@ bool build_dense(const HostModel& m, const mk_task_desc* tasks, int ntask, const
         memcpy(P.quat1, &m.geom_quat[4 * g1], 32); memcpy(P.quat2, &m.geom_quat[4 * g2], 32);
         P.gain = L.gain; P.d_min = L.minimum_distance_from_collisions;
         P.d_detect = L.collision_detection_distance; P.relax = L.bound_relaxation;
+        bool cvx = false;
+        std::string ignore;
+        pair_supported(m, g1, g2, &cvx, ignore);
+        P.convex = cvx ? 1 : 0;
+        auto shape_info = [&](int g, double* bc, double* rb, int32_t* vadr, int32_t* vnum, double* mean, double* ext) {
+          const int t = m.geom_type[g];
+          const double* sz = &m.geom_size[3 * g];
+          bc[0] = bc[1] = bc[2] = 0.0;
+          mean[0] = mean[1] = mean[2] = 0.0;
+          *vadr = 0; *vnum = 0;
+          *ext = std::max(std::fabs(sz[0]), std::max(std::fabs(sz[1]), std::fabs(sz[2])));
+          if (t == 2) *rb = sz[0];
+          else if (t == 3) *rb = sz[0] + sz[1];
+          else if (t == 4) *rb = *ext;
+          else if (t == 5) *rb = std::sqrt(sz[0] * sz[0] + sz[1] * sz[1]);
+          else if (t == 6) *rb = std::sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]);
+          else if (t == 7) {
+            const int k = m.geom_dataid[g];
+            *vadr = m.mesh_vertadr[k]; *vnum = m.mesh_vertnum[k];
+            memcpy(bc, &m.mesh_center[3 * k], 24);
+            *rb = m.mesh_radius[k];
+            double e = 0.0;
+            for (int i = 0; i < *vnum; ++i)
+              for (int a = 0; a < 3; ++a) {
+                const double x = m.mesh_vert[3 * (size_t)(*vadr + i) + a];
+                mean[a] += x;
+                e = std::max(e, std::fabs(x));
+              }
+            for (int a = 0; a < 3; ++a) mean[a] /= std::max(1, (int)*vnum);
+            *ext = e;
+          } else *rb = 0.0;
+        };
+        shape_info(g1, P.bc1, &P.rb1, &P.v1adr, &P.v1num, P.mean1, &P.ext1);
+        shape_info(g2, P.bc2, &P.rb2, &P.v2adr, &P.v2num, P.mean2, &P.ext2);
         pr.push_back(P);
       }
     }
@@ -761,6 +814,19 @@ int host_model_from_desc(const mk_model_desc* d, HostModel& h) {
   h.geom_size = copy_in(d->geom_size, 3 * h.ngeom);
   h.geom_pos = copy_in(d->geom_pos, 3 * h.ngeom);
   h.geom_quat = copy_in(d->geom_quat, 4 * h.ngeom);
+  h.nmesh = d->nmesh > 0 ? d->nmesh : 0;
+  h.nmeshvert = d->nmeshvert > 0 ? d->nmeshvert : 0;
+  h.geom_dataid = d->geom_dataid ? copy_in(d->geom_dataid, h.ngeom) : std::vector<int32_t>(h.ngeom, -1);
+  h.mesh_vertadr = copy_in(d->mesh_vertadr, h.nmesh);
+  h.mesh_vertnum = copy_in(d->mesh_vertnum, h.nmesh);
+  h.mesh_vert = copy_in(d->mesh_vert, 3 * (size_t)h.nmeshvert);
+  h.mesh_center = copy_in(d->mesh_center, 3 * (size_t)h.nmesh);
+  h.mesh_radius = copy_in(d->mesh_radius, h.nmesh);
+  for (int g = 0; g < h.ngeom; ++g)
+    if (h.geom_dataid[g] >= h.nmesh) return fail(MK_ERR_INVALID, "geom %d: mesh id out of range", g);
+  for (int k = 0; k < h.nmesh; ++k)
+    if (h.mesh_vertadr[k] < 0 || h.mesh_vertnum[k] < 0 || h.mesh_vertadr[k] + h.mesh_vertnum[k] > h.nmeshvert)
+      return fail(MK_ERR_INVALID, "mesh %d: vertex range", k);
   // consistency checks the kernels rely on
   int nq = 0, nv = 0;
   for (int j = 0; j < h.njnt; ++j) {
@@ -825,7 +891,7 @@ int mk_model_create(const mk_model_desc* d, mk_model** out) {
   UP(body_parentid); UP(body_jntadr); UP(body_jntnum); UP(body_mocapid); UP(body_pos); UP(body_quat);
   UP(jnt_type); UP(jnt_qposadr); UP(jnt_dofadr); UP(jnt_bodyid); UP(jnt_limited); UP(jnt_pos); UP(jnt_axis);
   UP(jnt_range); UP(qpos0); UP(body_mass); UP(body_ipos);
-  UP(geom_bodyid); UP(geom_type); UP(geom_size); UP(geom_pos); UP(geom_quat);
+  UP(geom_bodyid); UP(geom_type); UP(geom_size); UP(geom_pos); UP(geom_quat); UP(mesh_vert);
 #undef UP
   if (rc == MK_OK) rc = upload(m->allocs, dof_qadr, &dv.dof_qadr);
   if (rc == MK_OK) rc = upload(m->allocs, dof_scalar, &dv.dof_scalar);

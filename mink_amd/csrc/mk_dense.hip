@@ -94,6 +94,11 @@ MK_GPU void wave_argmax(double& key, int& id) {
   id = __builtin_amdgcn_readlane(v.id, 63);
 }
 
+}  // namespace
+#include "mk_convex.h"
+MK_CVX void cvx_wave_argmax(double& key, int& id) { wave_argmax(key, id); }
+namespace {
+
 // ------------------------------------------------------------ geom distance ----
 struct Contact {
   double dist;
@@ -1277,7 +1282,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MK_DENSE_WPE
       }
       Contact ct;
       bool active = false;
-      if (lower < C.d_detect) {
+      if (C.convex) {
+        // no closed form for this pair (convex mesh, cylinder, ellipsoid): support mappings
+        const M3 r2 = q2m(qmul(q2, Q4{C.quat2[0], C.quat2[1], C.quat2[2], C.quat2[3]}));
+        const V3 b2c = x2 + mul(r2, v3(C.bc2[0], C.bc2[1], C.bc2[2]));
+        if (C.t1 == GEOM_PLANE) {
+          lower = dot(b2c - x1, col(r1, 2)) - C.rb2;
+        } else {
+          const V3 dd = b2c - (x1 + mul(r1, v3(C.bc1[0], C.bc1[1], C.bc1[2])));
+          lower = sqrt(dot(dd, dd)) - C.rb1 - C.rb2;
+        }
+        if (lower < C.d_detect) {
+          CvxShape SB;
+          SB.type = C.t2; SB.c = x2; SB.R = r2; SB.size = sz2;
+          SB.verts = m.mesh_vert + 3 * (long)C.v2adr; SB.nvert = C.v2num;
+          SB.mean = v3(C.mean2[0], C.mean2[1], C.mean2[2]); SB.ext = C.ext2;
+          if (C.t1 == GEOM_PLANE) {
+            cvx_plane_distance(lane, x1, col(r1, 2), SB, ct.dist, ct.p1, ct.p2);
+          } else {
+            CvxShape SA;
+            SA.type = C.t1; SA.c = x1; SA.R = r1; SA.size = sz1;
+            SA.verts = m.mesh_vert + 3 * (long)C.v1adr; SA.nvert = C.v1num;
+            SA.mean = v3(C.mean1[0], C.mean1[1], C.mean1[2]); SA.ext = C.ext1;
+            cvx_distance(lane, SA, SB, ct.dist, ct.p1, ct.p2);
+          }
+          active = ct.dist < C.d_detect;
+        }
+      } else if (lower < C.d_detect) {
         const M3 r2 = q2m(qmul(q2, Q4{C.quat2[0], C.quat2[1], C.quat2[2], C.quat2[3]}));
         active = geom_distance(lane, C.t1, x1, r1, sz1, C.t2, x2, r2, sz2, C.d_detect, ct);
       }

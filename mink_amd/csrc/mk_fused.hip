@@ -166,7 +166,11 @@ MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const do
   bool settled = bad;
   // (the cap is the same for warm and cold lanes, so the loop stays wave-uniform when the two
   // kinds share a wave; a lane is settled at most N rounds after its additions stop)
+#if defined(MK_AB_ROUNDCAP)
+  for (int round = 0; round < kGuessRounds + N + 2; ++round) {
+#else
   for (int round = 0; round < 6 + N + 2; ++round) {
+#endif
     if (!settled) {
       MK_STAT(1);
       // H is re-read from LDS every round on purpose: hoisting the loads would pin the

@@ -42,6 +42,7 @@ struct MkDevModel {
   const double *geom_size, *geom_pos, *geom_quat;
   const int32_t *path_adr, *path_len, *path_data;  // bodies from the root to each body
   const uint64_t* body_dofmask;                     // per body: bit d set when dof d is on the path root -> body
+  const double* mesh_vert;                          // hull vertices of all meshes [nmeshvert * 3]
 };
 
 constexpr int MK_DENSE_MAX_TASKS = 8;
@@ -90,6 +91,11 @@ struct MkDensePair {
   uint64_t mask1, mask2;       // ancestor-dof masks of the two bodies
   double size1[3], size2[3], pos1[3], pos2[3], quat1[4], quat2[4];
   double gain, d_min, d_detect, relax;
+  // bounding spheres (centre in the geom frame) for the cheap "far apart" test, and what the
+  // support-mapping route needs (convex != 0: no closed form for this pair)
+  double bc1[3], bc2[3], rb1, rb2;
+  int32_t convex, v1adr, v1num, v2adr, v2num, pad;
+  double mean1[3], mean2[3], ext1, ext2;
 };
 
 struct MkDenseProblem {

@@ -67,6 +67,13 @@ def _quat_mul(a, b) -> np.ndarray:
     ])
 
 
+def _quat_to_mat(q) -> np.ndarray:
+    w, x, y, z = q
+    return np.array([[w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z]])
+
+
 def _axisangle_quat(axis, angle: float) -> np.ndarray:
     axis = np.asarray(axis, dtype=np.float64)
     n = np.linalg.norm(axis)
@@ -134,6 +141,17 @@ class Model:
     geom_quat: np.ndarray = None
     geom_contype: np.ndarray = None
     geom_conaffinity: np.ndarray = None
+    geom_dataid: np.ndarray = None       # mesh id of a mesh geom, else -1
+    # convex hulls of the meshes that collision geoms use (vertices in the geom frame the
+    # MJCF gives, scale applied; MuJoCo itself re-centres meshes on their inertial frame and
+    # adjusts geom_pos / geom_quat to match, which leaves the geometry in the world unchanged)
+    nmesh: int = 0
+    mesh_names: List[str] = field(default_factory=list)
+    mesh_vertadr: np.ndarray = None
+    mesh_vertnum: np.ndarray = None
+    mesh_vert: np.ndarray = None         # [sum vertnum, 3]
+    mesh_center: np.ndarray = None       # [nmesh, 3] centre of a bounding sphere
+    mesh_radius: np.ndarray = None       # [nmesh]
     # keyframes
     key_names: List[str] = field(default_factory=list)
     key_qpos: np.ndarray = None
@@ -144,16 +162,17 @@ class Model:
         "body_ipos body_inertial_known jnt_type jnt_qposadr jnt_dofadr jnt_bodyid "
         "jnt_pos jnt_axis jnt_range jnt_limited qpos0 dof_bodyid dof_jntid "
         "dof_parentid site_bodyid site_pos site_quat geom_bodyid geom_type geom_size "
-        "geom_pos geom_quat geom_contype geom_conaffinity key_qpos"
+        "geom_pos geom_quat geom_contype geom_conaffinity geom_dataid mesh_vertadr mesh_vertnum "
+        "mesh_center mesh_radius key_qpos"
     ).split()
     _INT_ARRAYS = (
         "body_parentid body_jntadr body_jntnum body_dofadr body_dofnum body_weldid "
         "body_mocapid body_geomadr body_geomnum jnt_type jnt_qposadr jnt_dofadr "
         "jnt_bodyid dof_bodyid dof_jntid dof_parentid site_bodyid geom_bodyid "
-        "geom_type geom_contype geom_conaffinity"
+        "geom_type geom_contype geom_conaffinity geom_dataid mesh_vertadr mesh_vertnum"
     ).split()
-    _SCALARS = "name nq nv nbody njnt ngeom nsite nkey nmocap".split()
-    _LISTS = "body_names jnt_names site_names geom_names key_names".split()
+    _SCALARS = "name nq nv nbody njnt ngeom nsite nkey nmocap nmesh".split()
+    _LISTS = "body_names jnt_names site_names geom_names key_names mesh_names".split()
 
     # ---- name lookup (the reference uses mj_name2id / model.joint(name)) ----
     def body_id(self, name: str) -> int:
@@ -183,7 +202,8 @@ class Model:
     def from_dict(cls, d: dict) -> "Model":
         m = cls()
         for k in cls._SCALARS + cls._LISTS:
-            setattr(m, k, d[k])
+            if k in d:                      # tables written before a field existed keep its default
+                setattr(m, k, d[k])
         for k in cls._ARRAYS:
             v = d.get(k)
             if v is None:
@@ -212,15 +232,64 @@ class Model:
         self.jnt_axis = shape(self.jnt_axis, 3, np.float64)
         self.jnt_range = shape(self.jnt_range, 2, np.float64)
         self.key_qpos = shape(self.key_qpos, self.nq, np.float64) if self.nq else self.key_qpos
+        if self.geom_dataid is None:
+            self.geom_dataid = np.full(self.ngeom, -1, dtype=np.int32)
+        self.mesh_vertadr = shape(self.mesh_vertadr if self.mesh_vertadr is not None else [], 0, np.int32)
+        self.mesh_vertnum = shape(self.mesh_vertnum if self.mesh_vertnum is not None else [], 0, np.int32)
+        self.mesh_center = shape(self.mesh_center if self.mesh_center is not None else [], 3, np.float64)
+        self.mesh_radius = shape(self.mesh_radius if self.mesh_radius is not None else [], 0, np.float64)
+        self.mesh_vert = shape(self.mesh_vert if self.mesh_vert is not None else [], 3, np.float64)
 
     def save_json(self, path: str) -> None:
+        """The table as JSON; hull vertices go to a binary side file <path minus .json>.meshes.npz."""
         with open(path, "w") as f:
             json.dump(self.to_dict(), f, indent=0)
+        side = os.path.splitext(path)[0] + ".meshes.npz"
+        if self.mesh_vert is not None and len(self.mesh_vert):
+            np.savez_compressed(side, mesh_vert=np.asarray(self.mesh_vert, dtype=np.float64))
+        elif os.path.exists(side):
+            os.remove(side)
 
     @classmethod
     def load_json(cls, path: str) -> "Model":
         with open(path) as f:
-            return cls.from_dict(json.load(f))
+            m = cls.from_dict(json.load(f))
+        side = os.path.splitext(path)[0] + ".meshes.npz"
+        if os.path.exists(side):
+            with np.load(side) as z:
+                m.mesh_vert = np.asarray(z["mesh_vert"], dtype=np.float64).reshape(-1, 3)
+        return m
+
+
+def load_stl(path: str) -> np.ndarray:
+    """Triangles [n, 3, 3] of a binary or ASCII STL file."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if len(data) >= 84:
+        n = int(np.frombuffer(data[80:84], dtype="<u4")[0])
+        if 84 + 50 * n == len(data):
+            rec = np.frombuffer(data[84:], dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]))
+            return rec["v"].astype(np.float64)
+    verts = [[float(x) for x in line.split()[1:4]] for line in data.decode("ascii", "replace").splitlines()
+             if line.strip().startswith("vertex")]
+    return np.asarray(verts, dtype=np.float64).reshape(-1, 3, 3)
+
+
+def mesh_volume_and_com(tri: np.ndarray):
+    """Signed volume and centre of mass of a closed triangle mesh (divergence theorem)."""
+    a, b, c = tri[:, 0], tri[:, 1], tri[:, 2]
+    v6 = np.einsum("ij,ij->i", a, np.cross(b, c))
+    vol = v6.sum() / 6.0
+    com = ((a + b + c) / 4.0 * v6[:, None]).sum(axis=0) / 6.0 / vol if abs(vol) > 0 else tri.reshape(-1, 3).mean(axis=0)
+    return abs(vol), com
+
+
+def convex_hull_vertices(points: np.ndarray) -> np.ndarray:
+    """Vertices of the convex hull of a point set, in a reproducible (lexicographic) order."""
+    from scipy.spatial import ConvexHull
+    pts = np.unique(np.asarray(points, dtype=np.float64).reshape(-1, 3), axis=0)
+    hull = pts[ConvexHull(pts).vertices]
+    return hull[np.lexsort((hull[:, 2], hull[:, 1], hull[:, 0]))]
 
 
 class _Defaults:
@@ -291,9 +360,22 @@ class _Compiler:
                 self.autolimits = comp.get("autolimits") == "true"
             if comp.get("eulerseq") is not None:
                 self.eulerseq = comp.get("eulerseq")
+        self.meshdir = ""
+        for comp in root.findall("compiler"):
+            if comp.get("meshdir") is not None:
+                self.meshdir = comp.get("meshdir")
         self.defaults = _Defaults()
         for d in root.findall("default"):
             self.defaults.add(d, None)
+        self.base_dir = "."
+        self.meshes: List[dict] = []      # {"name", "file", "scale"}
+        for asset in root.findall("asset"):
+            for me in asset.findall("mesh"):
+                a = self.defaults.resolve("mesh", me.get("class", "main"), me.attrib)
+                fname = a.get("file", "")
+                name = a.get("name") or os.path.splitext(os.path.basename(fname))[0]
+                scale = (_floats(a.get("scale", "1 1 1")) + [1.0, 1.0, 1.0])[:3]
+                self.meshes.append({"name": name, "file": fname, "scale": np.array(scale)})
 
         self.bodies: List[dict] = []
         self.joints: List[dict] = []
@@ -407,6 +489,7 @@ class _Compiler:
                     "conaffinity": int(a.get("conaffinity", "1")),
                     "mass": float(a["mass"]) if "mass" in a else None,
                     "density": float(a.get("density", "1000")),
+                    "mesh": a.get("mesh"),
                 })
         for child in elem:
             if child.tag == "body":
@@ -579,7 +662,60 @@ class _Compiler:
         m.geom_contype = np.array([g["contype"] for g in geoms], dtype=np.int32)
         m.geom_conaffinity = np.array([g["conaffinity"] for g in geoms], dtype=np.int32)
 
-        # inertials: explicit <inertial> wins; else primitives; meshes unknown.
+        # meshes: triangles (scaled) when the file can be read; convex hulls for the meshes of
+        # geoms that can collide; volume / centre of mass for bodies without <inertial>
+        names = [me["name"] for me in self.meshes]
+        m.nmesh = len(self.meshes)
+        m.mesh_names = names
+        tris: List[Optional[np.ndarray]] = []
+        for me in self.meshes:
+            path = os.path.join(self.base_dir, self.meshdir, me["file"])
+            tris.append(load_stl(path) * me["scale"] if os.path.isfile(path) else None)
+        dataid = np.full(m.ngeom, -1, dtype=np.int32)
+        collides = np.zeros(m.nmesh, dtype=bool)
+        for gi, g in enumerate(geoms):
+            if g["type"] == GEOM_MESH and g.get("mesh") in names:
+                dataid[gi] = names.index(g["mesh"])
+                if g["contype"] or g["conaffinity"]:
+                    collides[dataid[gi]] = True
+        m.geom_dataid = dataid
+        vadr_m, vnum_m, verts, centers, radii = [], [], [], [], []
+        for k in range(m.nmesh):
+            vadr_m.append(sum(vnum_m))
+            if tris[k] is not None and collides[k]:
+                hull = convex_hull_vertices(tris[k])
+                lo, hi = hull.min(axis=0), hull.max(axis=0)
+                ctr = 0.5 * (lo + hi)
+                vnum_m.append(len(hull))
+                verts.append(hull)
+                centers.append(ctr)
+                radii.append(float(np.linalg.norm(hull - ctr, axis=1).max()))
+            else:
+                vnum_m.append(0)
+                centers.append(np.zeros(3))
+                radii.append(0.0)
+        m.mesh_vertadr = np.array(vadr_m, dtype=np.int32)
+        m.mesh_vertnum = np.array(vnum_m, dtype=np.int32)
+        m.mesh_vert = np.concatenate(verts, axis=0) if verts else np.zeros((0, 3))
+        m.mesh_center = np.array(centers, dtype=np.float64).reshape(-1, 3)
+        m.mesh_radius = np.array(radii, dtype=np.float64)
+        for gi, g in enumerate(geoms):      # geom_size of a mesh geom: half extents of its hull (as MuJoCo reports an aabb)
+            k = dataid[gi]
+            if k >= 0 and vnum_m[k] > 0:
+                h = m.mesh_vert[vadr_m[k]:vadr_m[k] + vnum_m[k]]
+                m.geom_size[gi] = 0.5 * (h.max(axis=0) - h.min(axis=0))
+
+        def mesh_mass(g):
+            k = names.index(g["mesh"]) if g.get("mesh") in names else -1
+            if k < 0 or tris[k] is None:
+                return None
+            vol, com = mesh_volume_and_com(tris[k])
+            rot = _quat_to_mat(g["quat"])
+            mass_g = g["mass"] if g["mass"] is not None else g["density"] * vol
+            return mass_g, g["pos"] + rot @ com
+
+        # inertials: explicit <inertial> wins; else the geoms' volumes (meshes: the volume the
+        # triangles enclose; unknown when the mesh file is not available).
         mass = np.zeros(nb)
         ipos = np.zeros((nb, 3))
         known = np.ones(nb, dtype=bool)
@@ -591,7 +727,7 @@ class _Compiler:
                 continue
             tot, acc = 0.0, np.zeros(3)
             for g in self.geoms_by_body[b]:
-                mc = self._geom_mass_and_com(g)
+                mc = mesh_mass(g) if g["type"] == GEOM_MESH else self._geom_mass_and_com(g)
                 if mc is None:
                     known[b] = False
                     continue
@@ -628,7 +764,9 @@ def load_mjcf(path: str) -> Model:
     tree = ET.parse(path)
     root = tree.getroot()
     _expand_includes(root, os.path.dirname(os.path.abspath(path)))
-    return _Compiler(root).compile()
+    comp = _Compiler(root)
+    comp.base_dir = os.path.dirname(os.path.abspath(path))
+    return comp.compile()
 
 
 _DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")

@@ -565,7 +565,27 @@ def mj_geomDistance(m, d, g1, g2, distmax):
     elif t1 == GEOM_BOX and t2 == GEOM_BOX:
         dist, p1, p2 = _closest_box_box(c1, r1, s1, c2, r2, s2)
     else:
-        raise NotImplementedError(f"geom pair types ({t1}, {t2})")
+        # no closed form: support mappings (oracle/convex.py); meshes by their hull vertices
+        from . import convex as cx
+
+        def shape(g, c, r):
+            sh = dict(type=int(m.geom_type[g]), pos=np.asarray(c, dtype=float), mat=np.asarray(r, dtype=float),
+                      size=np.asarray(m.geom_size[g], dtype=float))
+            if sh["type"] == cx.MESH:
+                k = int(m.geom_dataid[g])
+                if k < 0 or m.mesh_vertnum[k] == 0:
+                    raise NotImplementedError(f"mesh geom {g} has no hull vertices in the model table")
+                sh["verts"] = m.mesh_vert[m.mesh_vertadr[k]:m.mesh_vertadr[k] + m.mesh_vertnum[k]]
+            elif sh["type"] not in (cx.SPHERE, cx.CAPSULE, cx.ELLIPSOID, cx.CYLINDER, cx.BOX):
+                raise NotImplementedError(f"geom type {sh['type']}")
+            return sh
+
+        if t1 == GEOM_PLANE:
+            if t2 == GEOM_PLANE:
+                raise NotImplementedError("plane - plane pair")
+            dist, p1, p2 = cx.plane_distance(dict(pos=c1, mat=r1), shape(g2, c2, r2))
+        else:
+            dist, p1, p2 = cx.distance(shape(g1, c1, r1), shape(g2, c2, r2))
     if dist >= distmax:
         return distmax, fromto
     if swap:

@@ -11,13 +11,13 @@ for a in "$@"; do case "$a" in *MK_DENSE_*) dflags+=("$a");; *) fflags+=("$a");;
 if [ ${#dflags[@]} -gt 0 ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "${dflags[@]}" -c mink_amd/csrc/mk_dense.hip -o build_ab/dense_$name.o
 fi
-for f in mk_generic mk_dense mk_api; do
-  if [ ! -f build_ab/$f.o ] || [ mink_amd/csrc/$f.hip -nt build_ab/$f.o ] || [ mink_amd/csrc/mk_device.h -nt build_ab/$f.o ]; then
+for f in mk_generic mk_dense mk_lie mk_api; do
+  if [ ! -f build_ab/$f.o ] || [ mink_amd/csrc/$f.hip -nt build_ab/$f.o ] || [ mink_amd/csrc/mk_device.h -nt build_ab/$f.o ] || [ mink_amd/csrc/mk_generic.h -nt build_ab/$f.o ] || [ include/mink_amd.h -nt build_ab/$f.o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c mink_amd/csrc/$f.hip -o build_ab/$f.o &
   fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "${fflags[@]}" -c mink_amd/csrc/mk_fused.hip -o build_ab/fused_$name.o
 wait
 dobj=build_ab/mk_dense.o; [ ${#dflags[@]} -gt 0 ] && dobj=build_ab/dense_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared build_ab/fused_$name.o build_ab/mk_generic.o $dobj build_ab/mk_api.o -o build_ab/libmink_$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared build_ab/fused_$name.o build_ab/mk_generic.o $dobj build_ab/mk_lie.o build_ab/mk_api.o -o build_ab/libmink_$name.so
 echo build_ab/libmink_$name.so
