@@ -20,17 +20,16 @@ from .engine import DeviceModel
 from .lie import SE3, SO3
 from .mjcf import JNT_FREE, Model
 
-_DEVICE_MODELS: dict = {}
-
-
 def device_model(model: Model, device) -> DeviceModel:
-    """One uploaded copy of a model per (model object, device)."""
-    key = (id(model), str(device))
-    dm = _DEVICE_MODELS.get(key)
-    if dm is None or dm.model is not model:
+    """One uploaded copy of a model per (model object, device).  The copies are kept on the
+    model object itself, so they (and their device tables and cached problems) go away with
+    the model instead of living as long as the process."""
+    cache = model.__dict__.setdefault("_device_models", {})
+    dm = cache.get(str(device))
+    if dm is None:
         dm = DeviceModel(model, device)
         dm.problem_cache = {}
-        _DEVICE_MODELS[key] = dm
+        cache[str(device)] = dm
     return dm
 
 
@@ -186,13 +185,38 @@ class Configuration:
             raise exceptions.InvalidFrame(frame_name=frame_name, frame_type=frame_type, model=self.model)
         return fid
 
+    def _mocap_frame(self, frame_type: str, fid: int):
+        """(mocap id, pose of the frame in its body) when the frame sits on a mocap body, else
+        None.  Such a body is placed by ``data.mocap_pos / mocap_quat`` (mj_kinematics reads
+        them), which live on the host side of this API: its frames are composed here and never
+        reach the kernels (a task or limit that names one is refused by the library)."""
+        m = self.model
+        body = {"body": lambda i: i, "geom": lambda i: int(m.geom_bodyid[i]), "site": lambda i: int(m.site_bodyid[i])}[frame_type](fid)
+        mid = int(m.body_mocapid[body])
+        if mid < 0:
+            return None
+        local = np.array([1.0, 0, 0, 0, 0, 0, 0])
+        if frame_type == "geom":
+            local = np.concatenate([m.geom_quat[fid], m.geom_pos[fid]])
+        elif frame_type == "site":
+            local = np.concatenate([m.site_quat[fid], m.site_pos[fid]])
+        return mid, local
+
     def get_frame_jacobian(self, frame_name: str, frame_type: str):
         """Body-frame Jacobian [.., 6, nv], rows (linear; angular)."""
         fid = self._frame_id(frame_name, frame_type)
+        if self._mocap_frame(frame_type, fid) is not None:      # no joint moves a mocap body
+            return self._out(torch.zeros((self.batch_size, 6, self.model.nv), dtype=torch.float64, device=self.device))
         return self._out(self.dmodel.frame_jacobian(self._q, consts.FRAME_TO_ENUM[frame_type], fid))
 
     def get_transform_frame_to_world(self, frame_name: str, frame_type: str) -> SE3:
         fid = self._frame_id(frame_name, frame_type)
+        mocap = self._mocap_frame(frame_type, fid)
+        if mocap is not None:
+            mid, local = mocap
+            body = SE3.from_rotation_and_translation(SO3(torch.as_tensor(self.data.mocap_quat[..., mid, :])),
+                                                     torch.as_tensor(self.data.mocap_pos[..., mid, :]))
+            return body @ SE3(torch.as_tensor(local).to(body.wxyz_xyz.device))
         pose = self.dmodel.frame_pose(self._q, consts.FRAME_TO_ENUM[frame_type], fid)
         return SE3(pose if self.batched else pose[0].cpu())
 

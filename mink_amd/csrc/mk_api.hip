@@ -185,6 +185,10 @@ int frame_body_and_local(const HostModel& m, int frame_type, int frame_id, int* 
   } else {
     return fail(MK_ERR_INVALID, "unknown frame type %d", frame_type);
   }
+  // A mocap body is placed by the caller's mocap_pos / mocap_quat (mj_kinematics reads them
+  // from MjData), which the kernels never see: frames on it are the host's business.
+  if (m.body_mocapid[*body] >= 0)
+    return fail(MK_ERR_UNSUPPORTED, "frame %d of type %d is attached to a mocap body, whose pose is not part of q", frame_id, frame_type);
   return MK_OK;
 }
 
@@ -452,6 +456,11 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
     if (D.dof[i].slot >= 0 || D.dof[i].kind != MK_DOF_SCALAR) continue;
     if (!pack(i, D.ddof[D.nd++])) { why = "several configuration limits on one dof"; return false; }
   }
+  // dofs whose Hessian entry is damping + mu and nothing else: free-joint dofs (zero Jacobian
+  // columns, posture rows zeroed) and scalar dofs outside the chain without posture cost
+  D.needs_diag = D.nfree > 0 ? 1 : 0;
+  for (int d = 0; d < D.nd; ++d)
+    if (!(D.ddof[d].W > 0.0)) D.needs_diag = 1;
   if (!X) return true;
 
   // ---- extension: relative frame term ----
@@ -656,6 +665,7 @@ bool build_dense(const HostModel& m, const mk_task_desc* tasks, int ntask, const
       for (int k = 0; k < L.n; ++k) {
         const int g1 = idx[2 * k], g2 = idx[2 * k + 1];
         if (g1 < 0 || g1 >= m.ngeom || g2 < 0 || g2 >= m.ngeom) { why = "geom id out of range"; return false; }
+        if (m.body_mocapid[m.geom_bodyid[g1]] >= 0 || m.body_mocapid[m.geom_bodyid[g2]] >= 0) { why = "collision geom on a mocap body, whose pose is not part of q"; return false; }
         std::string why_pair;
         if (!pair_supported(m, g1, g2, nullptr, why_pair)) { why = why_pair; return false; }
       }

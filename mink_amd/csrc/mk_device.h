@@ -72,7 +72,9 @@ struct MkPosture {
 
 struct MkFusedDesc {
   int32_t nq, nv, nc, nposture;
-  int32_t nfree, target_off, pad0, pad1;
+  int32_t nfree, target_off;
+  int32_t needs_diag;   // some dof gets its Hessian diagonal from damping + mu alone (no task cost, zero Jacobian column)
+  int32_t pad1;
   int32_t free_qadr[8];        // qpos address of each free joint (7 values)
   MkSegC segc[MK_MAX_CHAIN];
   int32_t seg_qadr[MK_MAX_CHAIN];     // qpos address of each chain slot (0 for padding slots)

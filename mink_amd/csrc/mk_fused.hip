@@ -570,7 +570,10 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
   {
     // non-finite chain q or target: the task error, hence every entry of c, is NaN
     // (input_bad: a non-finite coordinate outside the chain, found by the caller)
-    if (input_bad || !(fabs(diag + c[0]) < INFINITY)) {
+    // (also: damping = 0 with a vanishing Levenberg-Marquardt term leaves the dofs that carry
+    // no task cost with a zero Hessian entry -- the reference's QP backend rejects such a
+    // singular P, mink/solve_ik.py:101-103)
+    if (input_bad || !(fabs(diag + c[0]) < INFINITY) || (D->needs_diag && !(diag > 0.0))) {
       status = 3;
 #pragma unroll
       for (int i = 0; i < NC; ++i) x[i] = 0.0;

@@ -71,6 +71,13 @@ __global__ void frame_kernel(MkDevModel m, const double* __restrict__ q, int B, 
   V3 ps = st.p + mul(st.R, lpos);
   Q4 Qs = qmul(st.Q, lquat);
   if (pose) {
+    // The reference reads the frame's rotation matrix and converts it with mju_mat2Quat
+    // (mink/configuration.py:157-185, mink/lie/so3.py:80-84), which fixes the sign of the quaternion:
+    // the component its branch takes the square root for is positive.
+    const M3 Rm = q2m(Qs);
+    const double m0 = Rm.m[0], m4 = Rm.m[4], m8 = Rm.m[8];
+    const double lead = (m0 + m4 + m8 > 0.0) ? Qs.w : (m0 > m4 && m0 > m8) ? Qs.x : (m4 > m8) ? Qs.y : Qs.z;
+    if (lead < 0.0) Qs = Q4{-Qs.w, -Qs.x, -Qs.y, -Qs.z};
     double* o = pose + b * 7;
     o[0] = Qs.w; o[1] = Qs.x; o[2] = Qs.y; o[3] = Qs.z; o[4] = ps.x; o[5] = ps.y; o[6] = ps.z;
   }

@@ -769,6 +769,16 @@ def load_mjcf(path: str) -> Model:
     return comp.compile()
 
 
+def load_mjcf_string(xml: str, base_dir: str = ".") -> Model:
+    """Compile an MJCF document given as text (mujoco.MjModel.from_xml_string, as the
+    reference's tests build their small models); files it names are looked up under base_dir."""
+    root = ET.fromstring(xml)
+    _expand_includes(root, os.path.abspath(base_dir))
+    comp = _Compiler(root)
+    comp.base_dir = os.path.abspath(base_dir)
+    return comp.compile()
+
+
 _DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 

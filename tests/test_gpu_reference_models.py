@@ -1,0 +1,125 @@
+"""The reference's small test models through the whole stack on the GPU: MJCF front end ->
+device tables -> kernels, against the numpy restatement and the assertions of
+tests/test_configuration_limit.py, tests/test_velocity_limit.py and tests/test_utils.py."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+import mink_amd as mink
+import ref_models as R
+from mink_amd.mjcf import load_mjcf_string
+from oracle import ik_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_q(model, rng):
+    q = model.qpos0.copy()
+    for j in range(model.njnt):
+        a, t = model.jnt_qposadr[j], model.jnt_type[j]
+        if t == 0:
+            q[a:a + 3] += rng.uniform(-0.3, 0.3, 3)
+            qq = rng.normal(size=4)
+            q[a + 3:a + 7] = qq / np.linalg.norm(qq)
+        elif t == 1:
+            qq = rng.normal(size=4)
+            q[a:a + 4] = qq / np.linalg.norm(qq)
+        else:
+            lo, hi = (model.jnt_range[j] if model.jnt_limited[j] else (-1.0, 1.0))
+            q[a] = rng.uniform(lo + 0.1 * (hi - lo), hi - 0.1 * (hi - lo))
+    return q
+
+
+@pytest.mark.parametrize("xml", [R.SUBSET_LIMITED, R.FREEJOINT_AND_HINGE, R.BALL_AND_HINGE])
+def test_limits_and_solve_on_reference_models(xml):
+    model = load_mjcf_string(xml)
+    rng = np.random.default_rng(0)
+    dt = 1e-3
+    vel = {}
+    for j in range(model.njnt):
+        if model.jnt_type[j] == 1:
+            vel[model.jnt_names[j]] = (np.pi, np.pi / 2, np.pi / 4)
+        elif model.jnt_type[j] >= 2:
+            vel[model.jnt_names[j]] = (0.5,)
+    for trial in range(4):
+        q = rand_q(model, rng)
+        cfg = mink.Configuration(model, q)
+        ocfg = o.Configuration(model, q)
+        # ConfigurationLimit / VelocityLimit rows: shapes of the reference's tests, values of the restatement
+        climit = mink.ConfigurationLimit(model)
+        con = climit.compute_qp_inequalities(cfg, dt)
+        nb = len(climit.indices)
+        assert con.G.shape == (2 * nb, model.nv) and con.h.shape == (2 * nb,)
+        Gr, hr = o.ConfigurationLimit(model).inequalities(ocfg, dt)
+        np.testing.assert_array_equal(con.G, Gr)
+        np.testing.assert_allclose(con.h, hr, rtol=0, atol=1e-13)
+        vlimit = mink.VelocityLimit(model, vel)
+        con = vlimit.compute_qp_inequalities(cfg, dt)
+        nbv = len(vlimit.indices)
+        assert con.G.shape == (2 * nbv, model.nv)
+        np.testing.assert_allclose(con.h, np.concatenate([dt * vlimit.limit, dt * vlimit.limit]), rtol=0, atol=1e-18)
+        # a posture solve under both limits (ball joint: 3 dofs, free joint: no posture rows)
+        target = rand_q(model, rng)
+        task = mink.PostureTask(model, cost=1.0)
+        task.set_target(target)
+        v = mink.solve_ik(cfg, [task], dt, "quadprog", 1e-6, limits=[climit, vlimit])
+        otask = o.PostureTask(cost=np.ones(model.nv), target_q=target)
+        vr = o.solve_ik(ocfg, [otask], dt, damping=1e-6,
+                        limits=[o.ConfigurationLimit(model), o.VelocityLimit(model, {k: np.atleast_1d(x) for k, x in vel.items()})])
+        np.testing.assert_allclose(v, vr, rtol=0, atol=1e-8)
+        assert np.all(np.abs(v[vlimit.indices]) <= vlimit.limit + 1e-9)
+        # integrate on the manifold: quaternions stay unit
+        cfg.integrate_inplace(v, dt)
+        ocfg.integrate_inplace(vr, dt)
+        np.testing.assert_allclose(cfg.q, ocfg.q, rtol=0, atol=1e-12)
+
+
+def test_move_mocap_to_frame():
+    """tests/test_utils.py:62-103 of the reference."""
+    model = load_mjcf_string(R.MOCAP)
+    rng = np.random.default_rng(1)
+    q = rand_q(model, rng)
+    cfg = mink.Configuration(model, q)
+    body = cfg.get_transform_frame_to_world("test", "body")
+    mocap = cfg.get_transform_frame_to_world("mocap", "body")
+    np.testing.assert_allclose(mocap.wxyz_xyz.numpy(), [np.sqrt(0.5), np.sqrt(0.5), 0, 0, 0.5, 1, 5], atol=1e-15)
+    assert not np.allclose(mocap.translation().numpy(), body.translation().numpy())
+    mink.move_mocap_to_frame(model, cfg.data, "mocap", "test", "body")
+    moved = cfg.get_transform_frame_to_world("mocap", "body")
+    np.testing.assert_allclose(moved.wxyz_xyz.numpy(), body.wxyz_xyz.numpy(), rtol=0, atol=1e-15)
+    ref = o.Configuration(model, q).get_transform_frame_to_world("test", "body")
+    np.testing.assert_allclose(body.wxyz_xyz.numpy(), ref, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(mink.SE3.from_mocap_name(model, cfg.data, "mocap").wxyz_xyz.numpy(), ref, rtol=0, atol=1e-13)
+    assert float(np.abs(cfg.get_frame_jacobian("mocap", "body")).max()) == 0.0
+    # a task on a frame of the mocap body is refused by the library (its pose is not part of q)
+    task = mink.FrameTask("mocap", "body", 1.0, 1.0)
+    task.set_target(moved)
+    with pytest.raises(Exception) as e:
+        mink.solve_ik(cfg, [task], 1e-3, "quadprog", 1e-3)
+    assert "mocap" in str(e.value)
+    # batched: every configuration has its own mocap arrays
+    qb = np.stack([rand_q(model, rng) for _ in range(5)])
+    bcfg = mink.Configuration(model, qb)
+    mink.move_mocap_to_frame(model, bcfg.data, "mocap", "test", "body")
+    got = bcfg.get_transform_frame_to_world("mocap", "body").wxyz_xyz.cpu().numpy()
+    want = np.array([o.Configuration(model, x).get_transform_frame_to_world("test", "body") for x in qb])
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-13)
+
+
+def test_zero_damping_on_a_dof_without_cost_is_reported():
+    """damping = 0 with only a FrameTask without Levenberg-Marquardt term: the dofs outside the task's chain have a
+    zero Hessian entry; the reference's QP backend fails there (assert in mink/solve_ik.py:103)."""
+    from mink_amd.mjcf import load_builtin
+    model = load_builtin("tidybot_cube")
+    q = np.tile(model.key_qpos[0], (3, 1))
+    cfg = mink.Configuration(model, q)
+    task = mink.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=0.0)
+    task.set_target_from_configuration(cfg)
+    v = mink.solve_ik(cfg, [task], 0.005, "quadprog", 0.0, limits=[])
+    with pytest.raises(AssertionError):
+        cfg.check()
+    assert float(v.abs().max()) == 0.0
+    v = mink.solve_ik(cfg, [task], 0.005, "quadprog", 1e-12, limits=[])
+    cfg.check()
+    assert float(v.abs().max()) <= 1e-9
