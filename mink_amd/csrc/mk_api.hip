@@ -23,6 +23,9 @@ hipError_t mk_fused_launch_step(int nc, const MkFusedDesc* d_desc, int nq, const
 hipError_t mk_fused_launch_step_ext(int nc, const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nq, const double* q,
                                     const double* targets, int target_stride, double dt, double damping, int B,
                                     double* v, int32_t* status, hipStream_t stream);
+hipError_t mk_fused_launch_rows(int nc, const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nv, const double* q,
+                                const double* targets, int target_stride, double dt, double damping, int B, double* v,
+                                int32_t* status, hipStream_t stream);
 hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, double* q, const double* targets,
                                    int target_stride, double dt, double damping, int B, int max_iters,
                                    double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
@@ -525,6 +528,7 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
     } else {
       CB.kind = MK_CB_FREE;
       CB.free_qadr = m.jnt_qposadr[m.body_jntadr[b]];
+      CB.free_dofadr = m.jnt_dofadr[m.body_jntadr[b]];
     }
     for (int c : up) {
       if (anchor[c].slot != -2) { why = "collision geom on an inner body of the task chain"; return -1; }
@@ -540,6 +544,7 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
         S.hinge = (jt == MK_JNT_HINGE) ? 1.0 : 0.0;
         S.slide = 1.0 - S.hinge;
         S.qadr = m.jnt_qposadr[j];
+        S.dof = m.jnt_dofadr[j];
       }
     }
     if (CB.kind == MK_CB_FREE && CB.nseg > 0) { why = "joints below a free body"; return -1; }
@@ -582,6 +587,9 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
       P.g1 = s1;
       P.g2 = s2;
       P.d_detect = L.collision_detection_distance;
+      P.d_min = L.minimum_distance_from_collisions;
+      P.gain = L.gain;
+      P.relax = L.bound_relaxation;
     }
   }
   return true;
@@ -1053,12 +1061,19 @@ int mk_solve_ik_batch(const mk_problem* p, const double* d_q, const double* d_ta
   if (!d_q || !d_v || !d_status) return fail(MK_ERR_INVALID, "null argument");
   if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
   if (p->staged) {
-    // Structured kernel for every problem; it marks the ones with a collision pair within its
-    // detection distance, and only those go through the general kernel (which overwrites
-    // their velocity and status).
+    // Structured kernel for every problem; it marks the ones with a collision pair that may be
+    // within its detection distance.  Those go through the lane-per-problem kernel that builds the
+    // collision rows and solves the QP with them, and what that one leaves pending (more rows than
+    // it keeps, a pair type without a lane routine, no convergence) through the general kernel;
+    // both overwrite velocity and status of the problems they finish.
     MK_HIP(mk_fused_launch_step_ext(p->nc_kernel, p->d_fused, p->d_ext, p->info.nq, d_q, d_targets, p->info.target_stride,
                                     dt, damping, B, d_v, d_status, static_cast<hipStream_t>(stream)));
-    if (p->h_ext.ncpair > 0)
+    static const bool lane_rows = getenv("MK_NO_LANE_ROWS") == nullptr;   // tuning / tests: skip the middle stage
+    if (p->h_ext.ncpair > 0 && lane_rows)
+      MK_HIP(mk_fused_launch_rows(p->nc_kernel, p->d_fused, p->d_ext, p->info.nv, d_q, d_targets, p->info.target_stride,
+                                  dt, damping, B, d_v, d_status, static_cast<hipStream_t>(stream)));
+    static const bool general_stage = getenv("MK_NO_GENERAL_STAGE") == nullptr;   // tuning: leave the rest pending
+    if (p->h_ext.ncpair > 0 && general_stage)
       MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets,
                              p->info.target_stride, dt, damping, B, nullptr, nullptr, nullptr, nullptr, d_v, d_status, -1,
                              nullptr, nullptr, static_cast<hipStream_t>(stream), nullptr, false, true));

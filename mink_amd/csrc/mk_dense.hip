@@ -96,161 +96,59 @@ MK_GPU void wave_argmax(double& key, int& id) {
 
 }  // namespace
 #include "mk_convex.h"
+#include "mk_geom.h"
 MK_CVX void cvx_wave_argmax(double& key, int& id) { wave_argmax(key, id); }
 namespace {
 
 // ------------------------------------------------------------ geom distance ----
-struct Contact {
-  double dist;
-  V3 p1, p2;
-};
-
-MK_GPU V3 box_closest(V3 p, V3 c, const M3& r, V3 h) {
-  V3 loc = mulT(r, p - c);
-  loc.x = fmin(fmax(loc.x, -h.x), h.x);
-  loc.y = fmin(fmax(loc.y, -h.y), h.y);
-  loc.z = fmin(fmax(loc.z, -h.z), h.z);
-  return c + mul(r, loc);
-}
-
-MK_GPU void seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3& c1, V3& c2) {
-  const V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
-  const double a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
-  const double eps = 1e-30;
-  double s, t;
-  if (a <= eps && e <= eps) {
-    s = t = 0.0;
-  } else if (a <= eps) {
-    s = 0.0;
-    t = fmin(fmax(f / e, 0.0), 1.0);
-  } else {
-    const double c = dot(d1, r);
-    if (e <= eps) {
-      t = 0.0;
-      s = fmin(fmax(-c / a, 0.0), 1.0);
-    } else {
-      const double b = dot(d1, d2);
-      const double den = a * e - b * b;
-      s = den > eps ? fmin(fmax((b * f - c * e) / den, 0.0), 1.0) : 0.0;
-      t = (b * s + f) / e;
-      if (t < 0.0) {
-        t = 0.0;
-        s = fmin(fmax(-c / a, 0.0), 1.0);
-      } else if (t > 1.0) {
-        t = 1.0;
-        s = fmin(fmax((b - c) / a, 0.0), 1.0);
-      }
-    }
-  }
-  c1 = p1 + s * d1;
-  c2 = p2 + t * d2;
-}
-
-MK_GPU V3 col(const M3& r, int i) { return v3(r.m[i], r.m[3 + i], r.m[6 + i]); }
-MK_GPU double comp(V3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
-MK_GPU V3 box_vertex(V3 c, const M3& r, V3 h, int k) {
-  // k = 4*bx + 2*by + bz with sign -1 for bit 0, +1 for bit 1
-  V3 s = v3((k & 4) ? h.x : -h.x, (k & 2) ? h.y : -h.y, (k & 1) ? h.z : -h.z);
-  return c + mul(r, s);
-}
-MK_GPU void box_edge(V3 c, const M3& r, V3 h, int e, V3& a0, V3& a1) {
-  // e = 4*a + 2*sb + sc over axis a and the signs of the two other axes b=(a+1)%3, c=(a+2)%3
-  const int a = e >> 2, b = (a + 1) % 3, cc = (a + 2) % 3;
-  const double sb = (e & 2) ? 1.0 : -1.0, sc = (e & 1) ? 1.0 : -1.0;
-  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-  const double hh[3] = {h.x, h.y, h.z};
-  lo[b] = hi[b] = sb * hh[b];
-  lo[cc] = hi[cc] = sc * hh[cc];
-  lo[a] = -hh[a];
-  hi[a] = hh[a];
-  a0 = c + mul(r, v3(lo[0], lo[1], lo[2]));
-  a1 = c + mul(r, v3(hi[0], hi[1], hi[2]));
-}
-
 // Signed distance and witness points of two oriented boxes, computed by the whole wave:
 // separating-axis test for overlap (one candidate axis per lane; penetration = smallest
-// overlap, witnesses around the midpoint of the two support points), otherwise exact
-// closest points over the 8 + 8 vertex-box and 12 x 12 edge-edge candidates, spread over
-// the lanes.  Candidates are numbered in a fixed order and the first strict minimum wins,
-// so the result does not depend on how they are distributed.  A separated pair whose gap
-// along some candidate axis is already >= distmax returns that gap (the caller only needs
-// to know that the pair is out of range).
+// overlap, witnesses around the midpoint of the two support points), otherwise the closest
+// points over the vertex-box candidates and the support edges of the widest cross-product axis,
+// one candidate per lane.  Candidates are numbered in a fixed order and the first strict minimum
+// wins, so the result does not depend on how they are distributed (box_box_lane is the same
+// search by one lane).  A separated pair whose gap along some candidate axis is already
+// >= distmax returns that gap (the caller only needs to know that the pair is out of range).
 MK_GPU Contact box_box_wave(int lane, V3 c1, const M3& r1, V3 h1, V3 c2, const M3& r2, V3 h2, double distmax) {
   const V3 d = c2 - c1;
   double overlap = INFINITY;
   V3 axis = v3(1, 0, 0);
   bool sep = false;
-  if (lane < 15) {
-    V3 ax;
-    if (lane < 3) ax = col(r1, lane);
-    else if (lane < 6) ax = col(r2, lane - 3);
-    else ax = cross(col(r1, (lane - 6) / 3), col(r2, (lane - 6) % 3));
-    const double n2 = dot(ax, ax);
-    if (n2 >= 1e-12) {
-      ax = (1.0 / sqrt(n2)) * ax;
-      const V3 a1 = mulT(r1, ax), a2 = mulT(r2, ax);
-      const double ra = fabs(a1.x) * h1.x + fabs(a1.y) * h1.y + fabs(a1.z) * h1.z;
-      const double rb = fabs(a2.x) * h2.x + fabs(a2.y) * h2.y + fabs(a2.z) * h2.z;
-      const double proj = dot(d, ax);
-      overlap = ra + rb - fabs(proj);
-      sep = overlap < 0.0;
-      axis = proj >= 0.0 ? ax : neg(ax);
-    }
-  }
+  if (lane < 15 && box_box_axis(lane, d, r1, h1, r2, h2, overlap, axis)) sep = overlap < 0.0;
+  else overlap = INFINITY;
   Contact ct;
   if (__ballot(sep) == 0ull) {
     int id = lane;
     wave_argmin(overlap, id);
-    const V3 n = bcast3(axis, id);
-    const V3 a1 = mulT(r1, n), a2 = mulT(r2, n);
-    // support features along n: a component of n that vanishes in a box frame selects the
-    // middle of that extent (face / edge centre), not an arbitrary vertex
-    auto sg = [](double a) { return fabs(a) < 1e-9 ? 0.0 : (a > 0.0 ? 1.0 : -1.0); };
-    const V3 s1 = c1 + mul(r1, v3(sg(a1.x) * h1.x, sg(a1.y) * h1.y, sg(a1.z) * h1.z));
-    const V3 s2 = c2 + mul(r2, v3(-sg(a2.x) * h2.x, -sg(a2.y) * h2.y, -sg(a2.z) * h2.z));
-    const V3 pos = 0.5 * (s1 + s2);
-    ct.dist = -overlap;
-    ct.p1 = pos - (0.5 * ct.dist) * n;
-    ct.p2 = pos + (0.5 * ct.dist) * n;
+    return box_box_penetration(c1, r1, h1, c2, r2, h2, overlap, bcast3(axis, id));
+  }
+  // the gap along a separating axis is a lower bound of the distance: a pair that is
+  // farther apart than distmax along any of them is done without the closest-point search
+  double gap = (lane < 15 && overlap < INFINITY) ? -overlap : -INFINITY;
+  int gid = lane;
+  wave_argmax(gap, gid);
+  if (gap >= distmax) {
+    ct.dist = gap;
+    ct.p1 = c1;
+    ct.p2 = c2;
     return ct;
   }
-  {
-    // the gap along a separating axis is a lower bound of the distance: a pair that is
-    // farther apart than distmax along any of them is done without the closest-point search
-    double gap = (lane < 15 && overlap < INFINITY) ? -overlap : -INFINITY;
-    int gid = lane;
-    wave_argmax(gap, gid);
-    if (gap >= distmax) {
-      ct.dist = gap;
-      ct.p1 = c1;
-      ct.p2 = c2;
-      return ct;
-    }
-  }
+  // the cross-product axis with the widest gap (first one among equals)
+  double xgap = (lane >= 6 && lane < 15 && overlap < INFINITY) ? -overlap : -INFINITY;
+  int kx = (lane >= 6 && lane < 15 && overlap < INFINITY) ? lane : -1;
+  wave_argmax(xgap, kx);
+  const V3 nx = bcast3(axis, kx >= 0 ? kx : 0);
   double best = INFINITY;
   int bi = 1 << 30;
   V3 p1 = c1, p2 = c2;
-  for (int cnd = lane; cnd < 160; cnd += 64) {
-    V3 u, w;
-    if (cnd < 8) {
-      u = box_vertex(c1, r1, h1, cnd);
-      w = box_closest(u, c2, r2, h2);
-    } else if (cnd < 16) {
-      w = box_vertex(c2, r2, h2, cnd - 8);
-      u = box_closest(w, c1, r1, h1);
-    } else {
-      V3 a0, a1, b0, b1;
-      box_edge(c1, r1, h1, (cnd - 16) / 12, a0, a1);
-      box_edge(c2, r2, h2, (cnd - 16) % 12, b0, b1);
-      seg_seg(a0, a1, b0, b1, u, w);
-    }
-    const double dd = dot(u - w, u - w);
-    if (dd < best) { best = dd; bi = cnd; p1 = u; p2 = w; }
+  if (lane < MK_BOX_CANDIDATES) {
+    box_box_candidate(lane, kx, nx, c1, r1, h1, c2, r2, h2, p1, p2);
+    best = dot(p1 - p2, p1 - p2);
+    bi = lane;
   }
   wave_argmin(best, bi);
-  const int src = bi & 63;   // candidate c lives on lane c mod 64
-  ct.p1 = bcast3(p1, src);
-  ct.p2 = bcast3(p2, src);
+  ct.p1 = bcast3(p1, bi);
+  ct.p2 = bcast3(p2, bi);
   ct.dist = sqrt(best);
   return ct;
 }
@@ -260,17 +158,7 @@ MK_GPU Contact box_box_wave(int lane, V3 c1, const M3& r1, V3 h1, V3 c2, const M
 MK_GPU bool geom_distance(int lane, int t1, V3 c1, const M3& r1, V3 s1, int t2, V3 c2, const M3& r2, V3 s2,
                           double distmax, Contact& ct) {
   if (t1 == GEOM_PLANE && t2 == GEOM_BOX) {
-    const V3 n = col(r1, 2);
-    double best = INFINITY;
-    V3 pbest = c2;
-    for (int k = 0; k < 8; ++k) {
-      const V3 v = box_vertex(c2, r2, s2, k);
-      const double depth = dot(v - c1, n);
-      if (depth < best) { best = depth; pbest = v; }
-    }
-    ct.dist = best;
-    ct.p2 = pbest;
-    ct.p1 = pbest - best * n;
+    plane_box(c1, r1, c2, r2, s2, ct);
   } else if (t1 == GEOM_PLANE && t2 == GEOM_SPHERE) {
     const V3 n = col(r1, 2);
     ct.dist = dot(c2 - c1, n) - s2.x;
@@ -1009,11 +897,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MK_DENSE_WPE
   WLds s = carve(lds_base, n, mg, m.nq, target_stride, m.nbody);
   const int np = s.npad;
   const bool own = lane < n;
-  for (long b = blockIdx.x; b < B; b += gridDim.x) {
+  // Problems of this wave: b = blockIdx.x, + gridDim.x, ...; in the last stage of a staged solve
+  // only the ones still marked pending, found 64 status entries at a time (chunk c of the status
+  // array belongs to block c mod gridDim.x).
+  long next = blockIdx.x, chunk = (long)blockIdx.x * 64, chunk_cur = 0;
+  uint64_t pend = 0ull;
+  for (;;) {
+    long b;
+    if (only_pending) {
+      while (pend == 0ull && chunk < B) {
+        const long i = chunk + lane;
+        pend = __ballot(i < B && (status_out[i] & MK_STATUS_PENDING) != 0);
+        chunk_cur = chunk;
+        chunk += (long)gridDim.x * 64;
+      }
+      if (pend == 0ull) break;
+      b = chunk_cur + (__ffsll((unsigned long long)pend) - 1);
+      pend &= pend - 1ull;
+    } else {
+      b = next;
+      if (b >= B) break;
+      next += gridDim.x;
+    }
     // the iterated loop marks the problems that have left it: they are not touched again
     if (skip_flags && (skip_flags[b] & MK_ITER_DONE_BIT)) continue;
-    // second stage of a staged solve: only the problems the structured kernel left pending
-    if (only_pending && !(status_out[b] & MK_STATUS_PENDING)) continue;
     // ---- inputs, kinematics ----
     bool bad_lane = false;
     for (int i = lane; i < m.nq; i += 64) {

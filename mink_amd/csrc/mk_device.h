@@ -95,8 +95,11 @@ struct MkFusedDesc {
 // the root's slot, and its Jacobian is the frame Jacobian with the columns of the root's
 // ancestors set to zero.  CollisionAvoidanceLimit pairs are only screened here: a pair that
 // a conservative bound puts beyond its detection distance contributes no row
-// (mink/limits/collision_avoidance_limit.py:192-199), and a problem with a pair in range is
-// handed to the general kernel.
+// (mink/limits/collision_avoidance_limit.py:192-199).  A problem with a pair in range goes to
+// the lane-per-problem kernel that builds the pairs' rows and solves the QP with them, and from
+// there to the general kernel only when that one cannot finish it (more rows in range than it
+// keeps, a pair type it has no lane routine for, no convergence of its dual iteration).
+constexpr int MK_LANE_ROWS = 4;    // general rows per problem in the lane-per-problem solve
 constexpr int MK_MAX_CBODY = 6;    // bodies carrying collision geoms
 constexpr int MK_MAX_CSEG = 4;     // 1-dof joints between the chain's last body and such a body
 constexpr int MK_MAX_CGEOM = 12;
@@ -107,10 +110,10 @@ constexpr int32_t MK_STATUS_PENDING = 1 << 30;   // in a status entry: the gener
 struct MkCollSeg {        // like MkSegC: fixed transform, then motion about / along z
   double pq[4], pp[3];
   double hinge, slide;
-  int32_t qadr, pad;
+  int32_t qadr, dof;
 };
 struct MkCollBody {
-  int32_t kind, nseg, free_qadr, pad;
+  int32_t kind, nseg, free_qadr, free_dofadr;
   MkCollSeg seg[MK_MAX_CSEG];
   double tq[4], tp[3];    // fixed transform behind the last joint (WORLD: the world pose)
   double pad2;
@@ -123,6 +126,7 @@ struct MkCollGeom {
 struct MkCollPair {
   int32_t g1, g2;         // indices into cgeom, ordered by geom type
   double d_detect;
+  double d_min, gain, relax;   // row bound: gain (dist - d_min) / dt + relax, or relax at dist <= d_min
 };
 struct MkFusedExt {
   int32_t has_rel, rel_slot, rel_target_off, ncbody;

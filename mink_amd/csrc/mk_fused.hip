@@ -18,6 +18,7 @@
 // active sets run one instruction stream.
 #include "mk_device.h"
 #include "mk_generic.h"
+#include "mk_geom.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -424,18 +425,15 @@ MK_DEV bool rest_nonfinite(const MkFusedDesc* __restrict__ D, const double* row)
   return !(acc == 0.0);
 }
 
-// Builds and solves the QP of one problem from its chain kinematics. `row` is the
-// lane's q row in LDS. On return x holds dq of the chain dofs; the other dofs are
-// handled in place:
-//   INTEGRATE == false: row[dof] <- v[dof] for every non-chain dof (q is consumed)
-//   INTEGRATE == true : row[qadr] <- q (+) dt v for every non-chain dof, and their
-//                       velocity goes to vrow[dof] when vrow is not null
-template <int NC, bool INTEGRATE, bool REL = false>
-MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const double (&qc)[NC],
-                         ChainJac<NC>& cj, double dt, double inv_dt, double damping, double (&x)[NC],
-                         double* vrow, uint32_t& act, uint32_t& upper, bool warm, double* hstore,
-                         int hstride, bool input_bad = false, const MkFusedExt* __restrict__ X = nullptr,
-                         Twist e_rel = Twist{V3{0, 0, 0}, V3{0, 0, 0}}) {
+// QP of one problem from its chain kinematics: the dense block of H on the chain dofs goes
+// to the lane's LDS column (hstore), its linear term c and box bounds lo / hi to registers.
+// cj.J is consumed (it becomes the weighted task Jacobian).  Returns the diagonal every dof
+// shares: damping plus the Levenberg-Marquardt terms.  `row` is the lane's q.
+template <int NC, bool REL>
+MK_DEV double assemble_chain_qp(const MkFusedDesc* __restrict__ D, const double* row, const double (&qc)[NC],
+                                ChainJac<NC>& cj, double dt, double damping, double (&c)[NC], double (&lo)[NC],
+                                double (&hi)[NC], double* hstore, int hstride, const MkFusedExt* __restrict__ X,
+                                Twist e_rel, double& hacc) {
   // second frame term (RelativeFrameTask, mink/tasks/relative_frame_task.py:106-142): its block of
   // H goes to the lane's LDS column first, its share of c and of the diagonal to registers
   double c_rel[NC], diag_rel = 0.0;
@@ -517,10 +515,6 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
     }
   }
 
-  double c[NC], lo[NC], hi[NC];
-#if defined(MK_ABLATE) && MK_ABLATE == 2
-  double hacc = 0.0;
-#endif
   // one row of H per slot, together with the slot's posture terms and box bounds; padding
   // slots carry W = 1, A = B = 0 and infinite bounds: a decoupled entry with solution 0
   MkDofC dc = D->sdof[0];
@@ -554,6 +548,25 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
     MK_PIN3(c[i], hi[i], lo[i]);
     dc = nx;
   }
+  return diag;
+}
+
+// Builds and solves the QP of one problem from its chain kinematics. `row` is the
+// lane's q row in LDS. On return x holds dq of the chain dofs; the other dofs are
+// handled in place:
+//   INTEGRATE == false: row[dof] <- v[dof] for every non-chain dof (q is consumed)
+//   INTEGRATE == true : row[qadr] <- q (+) dt v for every non-chain dof, and their
+//                       velocity goes to vrow[dof] when vrow is not null
+template <int NC, bool INTEGRATE, bool REL = false>
+MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const double (&qc)[NC],
+                         ChainJac<NC>& cj, double dt, double inv_dt, double damping, double (&x)[NC],
+                         double* vrow, uint32_t& act, uint32_t& upper, bool warm, double* hstore,
+                         int hstride, bool input_bad = false, const MkFusedExt* __restrict__ X = nullptr,
+                         Twist e_rel = Twist{V3{0, 0, 0}, V3{0, 0, 0}}) {
+  double c[NC], lo[NC], hi[NC];
+  double hacc = 0.0;
+  const double diag = assemble_chain_qp<NC, REL>(D, row, qc, cj, dt, damping, c, lo, hi, hstore, hstride, X, e_rel, hacc);
+  MkDofC dc;
 
 #if defined(MK_ABLATE) && MK_ABLATE == 2
   // tuning build only: skip the QP, keep the assembled H / c / bounds alive
@@ -732,15 +745,16 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
   bool near = false;
   const int np = X->ncpair;
   for (int k = 0; k < np; ++k) {
-    const MkCollPair P = X->cpair[k];
+    const int g1 = X->cpair[k].g1, g2 = X->cpair[k].g2;
+    const double d_detect = X->cpair[k].d_detect;
     PoseQT a = gp[0], b = gp[0];
 #pragma unroll
     for (int g = 0; g < MK_MAX_CGEOM; ++g) {   // register arrays: select, do not index
-      if (g == P.g1) a = gp[g];
-      if (g == P.g2) b = gp[g];
+      if (g == g1) a = gp[g];
+      if (g == g2) b = gp[g];
     }
-    const MkCollGeom& G1 = X->cgeom[P.g1];
-    const MkCollGeom& G2 = X->cgeom[P.g2];
+    const MkCollGeom& G1 = X->cgeom[g1];
+    const MkCollGeom& G2 = X->cgeom[g2];
     double lower;
     if (G1.type == 0) {   // plane: height of the other geom's centre minus its extent along the normal
       const M3 R1 = q2m(a.q);
@@ -755,7 +769,7 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
     } else {
       const V3 d = b.t - a.t;
       lower = sqrt(dot(d, d)) - G1.rbound - G2.rbound;
-      if (G1.type == 6 && G2.type == 6 && lower < P.d_detect) {
+      if (G1.type == 6 && G2.type == 6 && lower < d_detect) {
         // two boxes: the largest gap along the 15 candidate separating axes
         const M3 R1 = q2m(a.q), R2 = q2m(b.q);
         const V3 h1 = v3(G1.size[0], G1.size[1], G1.size[2]), h2 = v3(G2.size[0], G2.size[1], G2.size[2]);
@@ -781,9 +795,502 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
         lower = fmax(lower, gap);
       }
     }
-    near |= !(lower >= P.d_detect);   // also true for a non-finite bound
+    near |= !(lower >= d_detect);   // also true for a non-finite bound
   }
   return near;
+}
+
+// ---- general rows in the lane-per-problem form ------------------------------------------
+// CollisionAvoidanceLimit rows of one lane's problem: row k over all nv dofs, element
+// (k, dof) at g[(k * nv + dof) * stride] (the lane's LDS column on the GPU), bound h[k].
+struct LaneRows {
+  double* g;
+  int stride, nv, n;
+  double h[MK_LANE_ROWS];
+  MK_DEV double& at(int k, int dof) const { return g[(k * nv + dof) * stride]; }
+};
+
+// World pose of collision body b; `tip` is the frame behind the chain's last joint.
+MK_DEV PoseQT coll_body_pose(const MkFusedExt* __restrict__ X, const double* row, PoseQT tip, int b) {
+  const MkCollBody& CB = X->cbody[b];
+  PoseQT p = PoseQT{Q4{1, 0, 0, 0}, v3(0, 0, 0)};
+  if (CB.kind == MK_CB_TIP) {
+    p = tip;
+    for (int sidx = 0; sidx < CB.nseg; ++sidx) {
+      const MkCollSeg& S = CB.seg[sidx];
+      p = pose_then(p, Q4{S.pq[0], S.pq[1], S.pq[2], S.pq[3]}, v3(S.pp[0], S.pp[1], S.pp[2]));
+      const double qv = row[S.qadr];
+      double sn, cs;
+      mk_sincos(0.5 * (S.hinge * qv), &sn, &cs);
+      p = pose_then(p, Q4{cs, 0.0, 0.0, sn}, v3(0.0, 0.0, S.slide * qv));
+    }
+  } else if (CB.kind == MK_CB_FREE) {
+    const double* f = row + CB.free_qadr;
+    p.t = v3(f[0], f[1], f[2]);
+    p.q = qnormalize(Q4{f[3], f[4], f[5], f[6]});
+  }
+  return pose_then(p, Q4{CB.tq[0], CB.tq[1], CB.tq[2], CB.tq[3]}, v3(CB.tp[0], CB.tp[1], CB.tp[2]));
+}
+
+// Adds s * n' Jp(point) to row m, Jp the translational Jacobian of `point` rigidly attached to
+// collision body b (mj_jac as used by compute_contact_normal_jacobian,
+// mink/limits/collision_avoidance_limit.py:83-110).  On the chain dofs the body-frame Jacobian of
+// the task frame (J, still unweighted; task frame at (tw, Rw)) gives the motion of every point
+// of the chain's last body: n' Rw (v_j + w_j x r) = (Rw'n).v_j + (r x Rw'n).w_j with r = Rw'(point - tw).
+template <int NC>
+MK_DEV void add_point_row(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const double* row,
+                          const double (&J)[6][NC], V3 tw, const M3& Rw, PoseQT tip, int b, V3 point, V3 n, double s,
+                          const LaneRows& R, int m) {
+  const MkCollBody& CB = X->cbody[b];
+  if (CB.kind == MK_CB_TIP) {
+    const V3 nt = mulT(Rw, n), r = mulT(Rw, point - tw);
+    const V3 mt = cross(r, nt);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int dof = D->seg_dof[j];
+      const double val = nt.x * J[0][j] + nt.y * J[1][j] + nt.z * J[2][j] + mt.x * J[3][j] + mt.y * J[4][j] + mt.z * J[5][j];
+      if (dof >= 0) R.at(m, dof) += s * val;
+    }
+    PoseQT f = tip;
+    for (int sidx = 0; sidx < CB.nseg; ++sidx) {
+      const MkCollSeg& S = CB.seg[sidx];
+      f = pose_then(f, Q4{S.pq[0], S.pq[1], S.pq[2], S.pq[3]}, v3(S.pp[0], S.pp[1], S.pp[2]));
+      const V3 z = qrot(f.q, v3(0, 0, 1));
+      const double val = S.hinge * dot(n, cross(z, point - f.t)) + S.slide * dot(n, z);
+      R.at(m, S.dof) += s * val;
+      const double qv = row[S.qadr];
+      double sn, cs;
+      mk_sincos(0.5 * (S.hinge * qv), &sn, &cs);
+      f = pose_then(f, Q4{cs, 0.0, 0.0, sn}, v3(0.0, 0.0, S.slide * qv));
+    }
+  } else if (CB.kind == MK_CB_FREE) {
+    // free joint: translation along the world axes, rotation about the body's own axes
+    const double* fq = row + CB.free_qadr;
+    const M3 Rb = q2m(qnormalize(Q4{fq[3], fq[4], fq[5], fq[6]}));
+    const V3 w = mulT(Rb, cross(point - v3(fq[0], fq[1], fq[2]), n));
+    const int d0 = CB.free_dofadr;
+    R.at(m, d0) += s * n.x; R.at(m, d0 + 1) += s * n.y; R.at(m, d0 + 2) += s * n.z;
+    R.at(m, d0 + 3) += s * w.x; R.at(m, d0 + 4) += s * w.y; R.at(m, d0 + 5) += s * w.z;
+  }
+}
+
+// Rows of the CollisionAvoidanceLimit pairs of one problem that are within their detection
+// distance (mink/limits/collision_avoidance_limit.py:187-210): G[k] = -n'(Jp2 - Jp1),
+// h[k] = gain (dist - d_min) / dt + relax (relax at dist <= d_min).  R.g must be zero on entry.
+// J is the unweighted body-frame Jacobian of the task frame at (Qw, tw, Rw).  Returns false when
+// the lane form cannot hold the problem: more than MK_LANE_ROWS rows, or a pair type without a
+// lane routine.
+template <int NC>
+MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const double* row,
+                           const double (&J)[6][NC], Q4 Qw, V3 tw, const M3& Rw, double dt, LaneRows& R) {
+  const Q4 postq = Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]};
+  PoseQT tip;
+  tip.q = qmul(Qw, qconj(postq));
+  tip.t = tw - qrot(tip.q, v3(D->post_pos[0], D->post_pos[1], D->post_pos[2]));
+  bool ok = true;
+  const int np = X->ncpair;
+  for (int k = 0; k < np; ++k) {
+    const MkCollPair P = X->cpair[k];
+    const MkCollGeom& G1 = X->cgeom[P.g1];
+    const MkCollGeom& G2 = X->cgeom[P.g2];
+    const PoseQT a = pose_then(coll_body_pose(X, row, tip, G1.body), Q4{G1.lq[0], G1.lq[1], G1.lq[2], G1.lq[3]},
+                               v3(G1.lp[0], G1.lp[1], G1.lp[2]));
+    const PoseQT b = pose_then(coll_body_pose(X, row, tip, G2.body), Q4{G2.lq[0], G2.lq[1], G2.lq[2], G2.lq[3]},
+                               v3(G2.lp[0], G2.lp[1], G2.lp[2]));
+    const M3 R1 = q2m(a.q);
+    const V3 s2 = v3(G2.size[0], G2.size[1], G2.size[2]);
+    // bounding spheres first (the bound behind which the general kernel skips the pair, too)
+    double lower;
+    if (G1.type == 0) {
+      lower = dot(b.t - a.t, col(R1, 2)) - G2.rbound;
+    } else {
+      const V3 d = b.t - a.t;
+      lower = sqrt(dot(d, d)) - G1.rbound - G2.rbound;
+    }
+    if (lower >= P.d_detect) continue;
+    Contact ct;
+    bool active;
+    if (G1.type == 0 && G2.type == 6) {
+      plane_box(a.t, R1, b.t, q2m(b.q), s2, ct);
+      active = ct.dist < P.d_detect;
+    } else if (G1.type == 6 && G2.type == 6) {
+      active = box_box_lane(a.t, R1, v3(G1.size[0], G1.size[1], G1.size[2]), b.t, q2m(b.q), s2, P.d_detect, ct);
+    } else if (G1.type == 0 && G2.type == 2) {
+      const V3 n = col(R1, 2);
+      ct.dist = dot(b.t - a.t, n) - s2.x;
+      ct.p2 = b.t - s2.x * n;
+      ct.p1 = ct.p2 - ct.dist * n;
+      active = ct.dist < P.d_detect;
+    } else if (G1.type == 2 && G2.type == 2) {
+      const V3 d = b.t - a.t;
+      double nrm = sqrt(dot(d, d));
+      const V3 ax = nrm < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nrm) * d;
+      if (nrm < MK_MINVAL) nrm = 0.0;
+      ct.dist = nrm - G1.size[0] - s2.x;
+      ct.p1 = a.t + G1.size[0] * ax;
+      ct.p2 = b.t - s2.x * ax;
+      active = ct.dist < P.d_detect;
+    } else {
+      ok = false;   // capsules: the general kernel
+      continue;
+    }
+    if (!active) continue;
+    if (R.n >= MK_LANE_ROWS) { ok = false; continue; }
+    const int m = R.n++;
+    const V3 dn = ct.p2 - ct.p1;
+    const double nn = sqrt(dot(dn, dn));
+    const V3 nrm = nn < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nn) * dn;
+    const double hval = ct.dist > P.d_min ? P.gain * (ct.dist - P.d_min) / dt + P.relax : P.relax;
+#pragma unroll
+    for (int i = 0; i < MK_LANE_ROWS; ++i)
+      if (i == m) R.h[i] = hval;
+    add_point_row<NC>(D, X, row, J, tw, Rw, tip, G2.body, ct.p2, nrm, -1.0, R, m);
+    add_point_row<NC>(D, X, row, J, tw, Rw, tip, G1.body, ct.p1, nrm, 1.0, R, m);
+  }
+  return ok;
+}
+
+// min 1/2 v'Hv + c'v  s.t. box bounds, G v <= h for the structured problem: H = the dense chain
+// block (LDS) + a diagonal on every other dof, at most MK_LANE_ROWS general rows.
+//
+// Dual iteration on the multipliers mu >= 0 of the general rows.  For fixed mu the problem is the
+// box-constrained one with linear term c + G'mu, which separates as before (box_qp on the chain
+// block, clamps elsewhere) and is solved exactly.  Its solution is piecewise linear in mu: on the
+// piece given by the current active box bounds, the row residuals move as r(mu') = r - S (mu' - mu)
+// with S = G Z (Z'HZ)^-1 Z'G' over the free dofs Z.  The step solves the linear complementarity
+// problem mu' >= 0, r(mu') <= 0, mu'.r(mu') = 0 of that piece exactly (enumeration of the 2^rows
+// active sets), then the box problem is solved again.  When the Karush-Kuhn-Tucker conditions
+// of the rows hold at a box solution, that solution is the optimum of the whole QP.  The iteration
+// visits pieces and normally ends in one to three steps; it is not guaranteed to (the caller
+// hands such a problem to the general kernel).
+// Returns true with x (chain dofs) and the other dofs' dq in vrow[dof] (already divided by dt).
+template <int NC>
+MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView H, const double (&c)[NC],
+                    const double (&lo)[NC], const double (&hi)[NC], double diag, double dt, double inv_dt,
+                    const LaneRows& R, double (&x)[NC], double* vrow) {
+  constexpr int M = MK_LANE_ROWS;
+  constexpr int kOuter = 8;
+  constexpr double kTol = 1e-12;
+  double mu[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) mu[k] = 0.0;
+  uint32_t act = 0u, upper = 0u;
+  bool done = false, good = false;
+  const int nd = D->nd, nrows = R.n;
+  const double rdiag = mk_rcp(diag);
+  for (int it = 0; it < kOuter; ++it) {
+    if (!done) {
+      // ---- box problem at mu ----
+      double cm[NC];
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int dof = D->seg_dof[i];
+        double sft = 0.0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) sft += mu[k] * R.at(k, dof >= 0 ? dof : 0);
+        cm[i] = c[i] + (dof >= 0 ? sft : 0.0);
+      }
+      asm volatile("" ::: "memory");
+      const int st = box_qp<NC>(H, cm, lo, hi, x, act, upper, it > 0);
+      double r[M];
+#pragma unroll
+      for (int k = 0; k < M; ++k) r[k] = k < nrows ? -R.h[k] : 0.0;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int dof = D->seg_dof[i];
+#pragma unroll
+        for (int k = 0; k < M; ++k) r[k] += (dof >= 0 ? R.at(k, dof) : 0.0) * x[i];
+      }
+      uint64_t clamped = 0ull;
+      bool infeasible = st != 0;
+      for (int d = 0; d < nd; ++d) {
+        const MkDofC dc = D->ddof[d];
+        const double qi = row[dc.qadr];
+        const double vb = dt * dc.vmax;
+        const double h = fmin(dc.gain * (dc.upper - qi), vb);
+        const double l = fmax(-(dc.gain * (qi - dc.lower)), -vb);
+        infeasible |= !(l <= h);
+        double g[M], sft = 0.0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) { g[k] = R.at(k, dc.dof); sft += mu[k] * g[k]; }
+        const double raw = -(dc.B * qi - dc.A + sft) * mk_rcp(diag + dc.W);
+        const double y = fmin(fmax(raw, l), h);
+        if (raw < l || raw > h) clamped |= 1ull << d;
+#pragma unroll
+        for (int k = 0; k < M; ++k) r[k] += g[k] * y;
+        vrow[dc.dof] = y * inv_dt;
+      }
+      for (int f = 0; f < D->nfree; ++f) {
+        for (int j = 0; j < 6; ++j) {
+          const int dof = D->free_dofadr[f] + j;
+          double g[M], sft = 0.0;
+#pragma unroll
+          for (int k = 0; k < M; ++k) { g[k] = R.at(k, dof); sft += mu[k] * g[k]; }
+          const double z = -sft * rdiag;
+#pragma unroll
+          for (int k = 0; k < M; ++k) r[k] += g[k] * z;
+          vrow[dof] = z * inv_dt;
+        }
+      }
+      // ---- optimality of the rows ----
+      bool kkt = true;
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        const double tol = kTol * fmax(1.0, fabs(R.h[k]));
+        if (k < nrows) kkt &= (mu[k] > 0.0) ? (fabs(r[k]) <= tol) : (r[k] <= tol);
+      }
+      if (infeasible) {
+        done = true;
+      } else if (kkt) {
+        done = true;
+        good = true;
+      } else {
+        // ---- S on the current piece ----
+        double L[NC * (NC + 1) / 2], Ld[NC];
+        asm volatile("" ::: "memory");
+        chol_masked<NC>(H, act, L, Ld);
+        double S[M][M];
+#pragma unroll
+        for (int k = 0; k < M; ++k)
+#pragma unroll
+          for (int l = 0; l < M; ++l) S[k][l] = 0.0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          double sk[NC];
+#pragma unroll
+          for (int i = 0; i < NC; ++i) {
+            const int dof = D->seg_dof[i];
+            sk[i] = (dof >= 0 && !((act >> i) & 1u)) ? R.at(k, dof) : 0.0;
+          }
+          chol_solve<NC>(L, Ld, sk);
+#pragma unroll
+          for (int i = 0; i < NC; ++i) {
+            const int dof = D->seg_dof[i];
+            const bool fr = dof >= 0 && !((act >> i) & 1u);
+#pragma unroll
+            for (int l = 0; l < M; ++l)
+              if (l >= k) S[k][l] += (fr ? R.at(l, dof) : 0.0) * sk[i];
+          }
+        }
+        for (int d = 0; d < nd; ++d) {
+          const MkDofC dc = D->ddof[d];
+          const double iw = ((clamped >> d) & 1ull) ? 0.0 : mk_rcp(diag + dc.W);
+          double g[M];
+#pragma unroll
+          for (int k = 0; k < M; ++k) g[k] = R.at(k, dc.dof);
+#pragma unroll
+          for (int k = 0; k < M; ++k)
+#pragma unroll
+            for (int l = 0; l < M; ++l)
+              if (l >= k) S[k][l] += g[k] * g[l] * iw;
+        }
+        for (int f = 0; f < D->nfree; ++f) {
+          for (int j = 0; j < 6; ++j) {
+            const int dof = D->free_dofadr[f] + j;
+            double g[M];
+#pragma unroll
+            for (int k = 0; k < M; ++k) g[k] = R.at(k, dof);
+#pragma unroll
+            for (int k = 0; k < M; ++k)
+#pragma unroll
+              for (int l = 0; l < M; ++l)
+                if (l >= k) S[k][l] += g[k] * g[l] * rdiag;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < M; ++k)
+#pragma unroll
+          for (int l = 0; l < k; ++l) S[k][l] = S[l][k];
+        // ---- complementarity problem of the piece: mu' >= 0, w = S mu' - b >= 0, mu'.w = 0 ----
+        double b[M];
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          b[k] = r[k];
+#pragma unroll
+          for (int l = 0; l < M; ++l) b[k] += S[k][l] * mu[l];
+        }
+        bool found = false;
+        double best[M];
+#pragma unroll
+        for (int k = 0; k < M; ++k) best[k] = 0.0;
+        for (int w = 0; w < (1 << M); ++w) {
+          if (found || (w >> nrows) != 0) continue;
+          // rows outside the set: unit row / column, zero right-hand side
+          double A[M][M], rhs[M];
+#pragma unroll
+          for (int k = 0; k < M; ++k) {
+            const bool ink = (w >> k) & 1;
+            rhs[k] = ink ? b[k] : 0.0;
+#pragma unroll
+            for (int l = 0; l < M; ++l) {
+              const bool inl = (w >> l) & 1;
+              A[k][l] = (ink && inl) ? S[k][l] : (k == l ? 1.0 : 0.0);
+            }
+          }
+          // Cholesky solve of the masked (symmetric positive definite) system
+          double Lc[M][M], m3[M];
+          bool spd = true;
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            double dj = A[j][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) dj -= Lc[j][k] * Lc[j][k];
+            spd &= dj > 1e-12 * A[j][j];   // dependent rows on this piece
+            const double rj = 1.0 / sqrt(fmax(dj, 1e-300));
+            Lc[j][j] = rj;
+#pragma unroll
+            for (int i = j + 1; i < M; ++i) {
+              double t = A[i][j];
+#pragma unroll
+              for (int k = 0; k < j; ++k) t -= Lc[i][k] * Lc[j][k];
+              Lc[i][j] = t * rj;
+            }
+          }
+          if (!spd) continue;
+#pragma unroll
+          for (int i = 0; i < M; ++i) {
+            double t = rhs[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) t -= Lc[i][k] * m3[k];
+            m3[i] = t * Lc[i][i];
+          }
+#pragma unroll
+          for (int i = M - 1; i >= 0; --i) {
+            double t = m3[i];
+#pragma unroll
+            for (int k = i + 1; k < M; ++k) t -= Lc[k][i] * m3[k];
+            m3[i] = t * Lc[i][i];
+          }
+          bool valid = true;
+#pragma unroll
+          for (int k = 0; k < M; ++k) {
+            const bool ink = (w >> k) & 1;
+            double wk = -b[k];
+#pragma unroll
+            for (int l = 0; l < M; ++l) wk += S[k][l] * m3[l];
+            if (ink) valid &= m3[k] >= 0.0;
+            else if (k < nrows) valid &= wk >= -kTol * fmax(1.0, fabs(R.h[k]));
+          }
+          if (valid) {
+            found = true;
+#pragma unroll
+            for (int k = 0; k < M; ++k) best[k] = ((w >> k) & 1) ? m3[k] : 0.0;
+          }
+        }
+        if (!found) {
+          done = true;
+        } else {
+#pragma unroll
+          for (int k = 0; k < M; ++k) mu[k] = best[k];
+        }
+      }
+    }
+    if (mk_wave_none(!done)) break;
+  }
+  return good;
+}
+
+// One pending problem of the staged solve in the lane form: chain kinematics, the collision rows
+// within range, QP assembly and the solve with those rows.  q is the problem's row of the batch
+// (read in place), hstore / gstore the lane's columns for H and the rows.  Returns true when
+// vrow [nv] holds the problem's velocity; false leaves the problem to the general kernel.
+template <int NC>
+MK_DEV bool rows_problem(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const double* row,
+                         const double* tg_row, double dt, double inv_dt, double damping, double* vrow, double* hstore,
+                         int hstride, double* gstore, int gstride) {
+  const double* tg = tg_row + D->target_off;
+  const Q4 Qt = Q4{tg[0], tg[1], tg[2], tg[3]};
+  const V3 pt = v3(tg[4], tg[5], tg[6]);
+  double qc[NC], x[NC];
+  load_chain_q<NC>(D, row, qc);
+  ChainJac<NC> cj;
+  Q4 Qw, Qcap = Q4{1, 0, 0, 0};
+  V3 tw, tcap = v3(0, 0, 0);
+  M3 Rw;
+  chain_jac_pose<NC, true>(D, qc, cj, Qw, tw, Rw, X->has_rel ? X->rel_slot : NC, &Qcap, &tcap);
+  cj.e = frame_error(Qw, tw, Rw, Qt, pt);
+  LaneRows R;
+  R.g = gstore;
+  R.stride = gstride;
+  R.nv = D->nv;
+  R.n = 0;
+#pragma unroll
+  for (int k = 0; k < MK_LANE_ROWS; ++k) R.h[k] = INFINITY;
+  for (int i = 0; i < MK_LANE_ROWS * D->nv; ++i) gstore[i * gstride] = 0.0;
+  const bool fits = collision_rows<NC>(D, X, row, cj.J, Qw, tw, Rw, dt, R);
+  double c[NC], lo[NC], hi[NC], hacc = 0.0, diag;
+  if (X->has_rel) {
+    const double* tr = tg_row + X->rel_target_off;
+    const Q4 Qrt = Q4{tr[0], tr[1], tr[2], tr[3]};
+    const V3 prt = v3(tr[4], tr[5], tr[6]);
+    const Q4 xqi = qconj(Q4{X->rel_xq[0], X->rel_xq[1], X->rel_xq[2], X->rel_xq[3]});
+    const Q4 Qrf = qmul(xqi, Qcap);
+    const V3 trf = qrot(xqi, tcap - v3(X->rel_xp[0], X->rel_xp[1], X->rel_xp[2]));
+    const M3 Rt = q2m(Qrt);
+    const Twist e_rel = se3_log(qmul(qconj(Qrt), Qrf), mulT(Rt, trf - prt));
+    diag = assemble_chain_qp<NC, true>(D, row, qc, cj, dt, damping, c, lo, hi, hstore, hstride, X, e_rel, hacc);
+  } else {
+    diag = assemble_chain_qp<NC, false>(D, row, qc, cj, dt, damping, c, lo, hi, hstore, hstride, X,
+                                        Twist{V3{0, 0, 0}, V3{0, 0, 0}}, hacc);
+  }
+  asm volatile("" ::: "memory");
+  bool good = rows_qp<NC>(D, row, HView{hstore, hstride}, c, lo, hi, diag, dt, inv_dt, R, x, vrow);
+  good &= fits && (diag > 0.0);
+  if (good) {
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+      if (D->seg_dof[k] >= 0) vrow[D->seg_dof[k]] = x[k] * inv_dt;
+  }
+  return good;
+}
+
+// Second stage of the staged solve: the problems the structured kernel left pending (a collision
+// pair may be in range), 64 of them per wave in the lane form.  Every wave scans its share of the
+// status array in chunks of 64 entries (chunk c belongs to block c mod gridDim.x), queues the
+// pending indices in LDS and works through the queue 64 problems at a time.  A problem it
+// finishes gets its velocity row and status 0; one it cannot finish stays pending.
+template <int NC>
+__global__ MK_KERNEL_ATTR void fused_rows_kernel(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X,
+                                                 const double* __restrict__ q, const double* __restrict__ targets,
+                                                 int target_stride, double dt, double damping, int B,
+                                                 double* __restrict__ v_out, int32_t* status_out) {
+  extern __shared__ double tile[];
+  constexpr int NH = NC * (NC + 1) / 2;
+  const int nq = D->nq, nv = D->nv;
+  const int lane = threadIdx.x;
+  double* hlds = tile + lane;
+  double* glds = tile + NH * 64 + lane;
+  int32_t* queue = reinterpret_cast<int32_t*>(tile + (NH + MK_LANE_ROWS * nv) * 64);   // 128 entries
+  const double inv_dt = 1.0 / dt;
+  const int nchunks = (B + 63) / 64;
+  int n = 0;
+  for (int ch = blockIdx.x;; ch += gridDim.x) {
+    const bool more = ch < nchunks;
+    if (more) {
+      const long idx = (long)ch * 64 + lane;
+      const bool pend = idx < B && (status_out[idx] & MK_STATUS_PENDING) != 0;
+      const uint64_t mask = __ballot(pend);
+      if (pend) queue[n + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)idx;
+      n += __popcll(mask);
+    }
+    __syncthreads();
+    while (n >= 64 || (!more && n > 0)) {
+      const int take = min(n, 64);
+      const bool valid = lane < take;
+      const long pb = queue[valid ? lane : 0];
+      // lanes without a problem of their own repeat the first one, stores included (same values)
+      const bool good = rows_problem<NC>(D, X, q + pb * nq, targets + pb * target_stride, dt, inv_dt, damping,
+                                         v_out + pb * nv, hlds, 64, glds, 64);
+      if (valid && good) status_out[pb] = 0;
+      const int rest = n - take;
+      const int32_t mv = lane < rest ? queue[64 + lane] : 0;
+      __syncthreads();
+      if (lane < rest) queue[lane] = mv;
+      n = rest;
+      __syncthreads();
+    }
+    if (!more) break;
+  }
 }
 
 // fused_step_kernel with the extension descriptor: an optional RelativeFrameTask term and the
@@ -1322,6 +1829,35 @@ hipError_t mk_fused_launch_step_ext(int nc, const MkFusedDesc* d_desc, const MkF
   switch (nc) {
 #define MK_CASE(N) \
   case N: return launch_step_ext<N>(d_desc, d_ext, nq, q, targets, target_stride, dt, damping, B, v, status, stream);
+    MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
+#undef MK_CASE
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <int NC>
+static hipError_t launch_rows(const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nv, const double* q,
+                              const double* targets, int target_stride, double dt, double damping, int B, double* v,
+                              int32_t* status, hipStream_t stream) {
+  // per wave: H and the general rows of 64 problems, and the queue of pending indices
+  const size_t lds = (size_t)64 * (NC * (NC + 1) / 2 + MK_LANE_ROWS * nv) * sizeof(double) + 128 * sizeof(int32_t);
+  // a model too wide for one wave's rows to fit the LDS of a compute unit skips this stage: its
+  // pending problems all go to the general kernel
+  if (lds > (size_t)160 * 1024) return hipSuccess;
+  if (hipError_t e = allow_lds<fused_rows_kernel<NC>>(lds); e != hipSuccess) return e;
+  // two resident waves per compute unit at this LDS size; each scans its chunks of the status array
+  const int blocks = std::max(1, std::min((B + 63) / 64, wave_slots() / 2));
+  hipLaunchKernelGGL(fused_rows_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, d_ext, q, targets,
+                     target_stride, dt, damping, B, v, status);
+  return hipGetLastError();
+}
+
+hipError_t mk_fused_launch_rows(int nc, const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nv, const double* q,
+                                const double* targets, int target_stride, double dt, double damping, int B, double* v,
+                                int32_t* status, hipStream_t stream) {
+  switch (nc) {
+#define MK_CASE(N) \
+  case N: return launch_rows<N>(d_desc, d_ext, nv, q, targets, target_stride, dt, damping, B, v, status, stream);
     MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
 #undef MK_CASE
     default: return hipErrorInvalidValue;

@@ -146,6 +146,46 @@ extern "C" int hostsim_iterate(const mk_model_desc* md, const mk_task_desc* task
   HS_DISPATCH(run_iterate, D, q, targets, stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status)
 }
 
+// The lane form of the staged solve's middle stage on every problem: rows of the collision pairs
+// in range + the QP with them.  good[b] = 0 where the lane form hands the problem on.
+template <int NC>
+int run_rows(const MkFusedDesc& D, const MkFusedExt& X, const double* q, const double* targets, int stride, double dt,
+             double damping, int B, double* v, int32_t* good, int32_t* nrows) {
+  double hbuf[MK_MAX_CHAIN * (MK_MAX_CHAIN + 1) / 2];
+  std::vector<double> gbuf((size_t)MK_LANE_ROWS * D.nv);
+  for (int b = 0; b < B; ++b) {
+    good[b] = rows_problem<NC>(&D, &X, q + (size_t)b * D.nq, targets + (size_t)b * stride, dt, 1.0 / dt, damping,
+                               v + (size_t)b * D.nv, hbuf, 1, gbuf.data(), 1) ? 1 : 0;
+    int n = 0;
+    for (int k = 0; k < MK_LANE_ROWS; ++k) {
+      bool any = false;
+      for (int i = 0; i < D.nv; ++i) any |= gbuf[(size_t)k * D.nv + i] != 0.0;
+      n += any;
+    }
+    if (nrows) nrows[b] = n;
+  }
+  return 0;
+}
+
+extern "C" int hostsim_solve_rows(const mk_model_desc* md, const mk_task_desc* tasks, int ntask,
+                                  const mk_limit_desc* limits, int nlimit, const double* q, const double* targets,
+                                  double dt, double damping, int B, double* v, int32_t* good, int32_t* nrows) {
+  static MkFusedDesc D;
+  static MkFusedExt X;
+  HostModel h;
+  int rc = host_model_from_desc(md, h);
+  if (rc != MK_OK) return rc;
+  std::string why;
+  int nk;
+  bool needs_ext = false;
+  if (!build_fused(h, tasks, ntask, limits, nlimit, D, &nk, why, &X, &needs_ext)) return fail(MK_ERR_UNSUPPORTED, "%s", why.c_str());
+  int stride = 0;
+  for (int t = 0; t < ntask; ++t)
+    stride += (tasks[t].type == MK_TASK_FRAME || tasks[t].type == MK_TASK_RELATIVE_FRAME) ? 7
+              : tasks[t].type == MK_TASK_COM ? 3 : 0;
+  HS_DISPATCH(run_rows, D, X, q, targets, stride, dt, damping, B, v, good, nrows)
+}
+
 // The device waypoint generator on B (current pose, goal pose) pairs (wxyz_xyz each):
 // commanded poses [B, 7] and reached flags [B].
 extern "C" void hostsim_waypoint_step(const double* cur, const double* goal, int B, double pos_thr, double pos_step,

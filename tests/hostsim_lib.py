@@ -80,3 +80,25 @@ def waypoint_step(cur, goal, pos_thr, pos_step, rot_thr):
     h.hostsim_waypoint_step(_ptr(cur), _ptr(goal), C.c_int(B), C.c_double(pos_thr), C.c_double(pos_step),
                             C.c_double(rot_thr), _ptr(cmd), _ptr(reached))
     return cmd, reached.astype(bool)
+
+
+def solve_rows(model, task_specs, limit_specs, q, targets, dt, damping):
+    """The lane form of the staged solve's middle stage (collision rows + QP with them) on
+    every problem: (v [B, nv], good [B], rows in range [B])."""
+    h = _load()
+    h.hostsim_solve_rows.restype = C.c_int
+    md, k1 = L.pack_model(model)
+    ta, k2 = L.pack_tasks(task_specs)
+    la, k3 = L.pack_limits(limit_specs)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    targets = np.ascontiguousarray(targets, dtype=np.float64)
+    B = q.shape[0]
+    v = np.zeros((B, model.nv))
+    good = np.zeros(B, dtype=np.int32)
+    nrows = np.zeros(B, dtype=np.int32)
+    rc = h.hostsim_solve_rows(C.byref(md), ta, C.c_int(len(task_specs)), la, C.c_int(len(limit_specs)), _ptr(q),
+                              _ptr(targets), C.c_double(dt), C.c_double(damping), C.c_int(B), _ptr(v), _ptr(good),
+                              _ptr(nrows))
+    if rc != 0:
+        raise RuntimeError(f"hostsim rc={rc}: {h.mk_last_error().decode()}")
+    return v, good, nrows

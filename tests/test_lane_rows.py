@@ -1,0 +1,71 @@
+"""The lane-per-problem solve with collision rows (middle stage of the staged solve), run on the
+CPU through the host build of the device functions, against the numpy restatement of
+mink.solve_ik with a CollisionAvoidanceLimit (mink/limits/collision_avoidance_limit.py:187-210,
+mink/solve_ik.py:68-105)."""
+import numpy as np
+import pytest
+
+import hostsim_lib as hs
+from mink_amd import workloads as W
+from mink_amd.mjcf import load_builtin
+from oracle import ik_oracle as o
+
+pytestmark = pytest.mark.skipif(not hs.available(), reason="tests/hostsim/libhostsim.so not built")
+
+
+def near_inputs(model, rng, n):
+    """Configurations with the cube a few centimetres from a gripper pad (the recipe of the
+    benchmark's config 4, with the numpy kinematics) and targets from an independent sample."""
+    q = W.sample_q(model, rng, n)
+    qs = W.sample_q(model, rng, n)
+    adr = int(model.jnt_qposadr[model.joint_id("interactive_obj_freejoint")])
+    tg = np.zeros((n, 14))
+    for i in range(n):
+        cfg = o.Configuration(model, q[i])
+        pad = cfg.get_transform_frame_to_world(W.PADS[rng.integers(0, 4)], "geom")
+        d = rng.normal(size=3)
+        q[i, adr:adr + 3] = pad[4:] + d / np.linalg.norm(d) * rng.uniform(0.03, 0.05)
+        qq = rng.normal(size=4)
+        q[i, adr + 3:adr + 7] = qq / np.linalg.norm(qq)
+        c2 = o.Configuration(model, qs[i])
+        t_world = c2.get_transform_frame_to_world("pinch_site", "site")
+        t_base = c2.get_transform_frame_to_world("base_link", "body")
+        tg[i, :7] = t_world
+        tg[i, 7:] = o.se3_multiply(o.se3_inverse(t_base), t_world)
+    return q, tg
+
+
+def oracle_solve(model, q, tg, with_collision=True):
+    tasks = [o.FrameTask("pinch_site", "site", 1.0, 1.0, 1.0, 1.0, tg[:7]),
+             o.RelativeFrameTask("pinch_site", "site", "base_link", "body", 1.0, 1.0, 1.0, 0.0, tg[7:]),
+             o.PostureTask(W.posture_cost(model), W.home_q(model))]
+    limits = [o.ConfigurationLimit(model, gain=0.95),
+              o.VelocityLimit(model, {k: np.atleast_1d(v) for k, v in W.VELOCITY_LIMITS.items()})]
+    coll = o.CollisionAvoidanceLimit(model, [(list(W.PADS), ["cube_geom", "floor"])])
+    if with_collision:
+        limits.append(coll)
+    cfg = o.Configuration(model, q)
+    v = o.solve_ik(cfg, tasks, W.DT, damping=W.DAMPING, limits=limits)
+    G, h = coll.inequalities(cfg, W.DT)
+    return v, G, h
+
+
+def test_lane_rows_against_oracle():
+    model = load_builtin("tidybot_cube")
+    rng = np.random.default_rng(3)
+    n = 48
+    q, tg = near_inputs(model, rng, n)
+    tasks, limits = W.config4_specs(model)
+    v, good, nrows = hs.solve_rows(model, tasks, limits, q, tg, W.DT, W.DAMPING)
+    n_binding = 0
+    for i in range(n):
+        vr, G, h = oracle_solve(model, q[i], tg[i])
+        assert nrows[i] == int(np.isfinite(h).sum()), (i, nrows[i], h)
+        if not good[i]:
+            assert nrows[i] > 4, f"problem {i} with {nrows[i]} rows was handed on"
+            continue
+        np.testing.assert_allclose(v[i], vr, rtol=0, atol=2e-9, err_msg=f"problem {i}, rows {nrows[i]}")
+        v0, _, _ = oracle_solve(model, q[i], tg[i], with_collision=False)
+        n_binding += int(np.abs(v0 - vr).max() > 1e-7)
+    assert good.sum() >= n - 2
+    assert (nrows > 0).sum() >= n // 2 and n_binding >= 5, (nrows, n_binding)

@@ -15,4 +15,5 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WA
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $BENCH > $O/pmc_fetch.log 2>&1 || exit 4
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $BENCH > $O/pmc_write.log 2>&1 || exit 5
 timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $O/pmc_grbm -- $BENCH > $O/pmc_grbm.log 2>&1 || exit 6
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_all -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/kt_all.log 2>&1 || exit 7
 echo profile_done

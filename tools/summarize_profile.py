@@ -6,7 +6,11 @@ import csv
 import glob
 import json
 import os
+import hashlib
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import code_object_meta
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 KERNEL = "fused_iterate_kernel"
@@ -23,14 +27,30 @@ def read_counters(d):
     return out
 
 
-def main(tag, name, solves_per_launch):
+def kernel_source_hash():
+    """Same digest as bench.py: the sources the timed kernel is built from."""
+    h = hashlib.sha256()
+    for f in ("mk_fused.hip", "mk_device.h"):
+        with open(os.path.join(ROOT, "mink_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
+def main(tag, name, solves_per_launch, iterations=50):
     src = os.path.join(ROOT, "gpurun_out", tag)
-    res = {"tag": tag, "kernel": KERNEL + "<10>", "solves_per_launch": solves_per_launch}
+    res = {"tag": tag, "kernel": KERNEL + "<10>", "solves_per_launch": solves_per_launch,
+           "kernel_source_sha256": kernel_source_hash()}
+    meta = code_object_meta.collect()      # from build/obj/*.o: the binary the run loaded was linked from these
+    res["code_object"] = {k: v for k, v in meta.items() if k.startswith(KERNEL + "<10>")}
     stats = glob.glob(os.path.join(src, "kt", "**", "*_kernel_stats.csv"), recursive=True)
     rows = list(csv.DictReader(open(stats[0])))
     lines = ["| kernel | calls | avg ns | total % |", "|---|---|---|---|"]
     for r in rows[:8]:
-        lines.append(f"| {r['Name'][:90]} | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['Percentage']} |")
+        lines.append(f"| {short(r['Name'])[:90]} | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['Percentage']} |")
         if KERNEL in r["Name"]:
             res["avg_ns"] = float(r["AverageNs"])
             res["calls"] = int(r["Calls"])
@@ -59,18 +79,36 @@ def main(tag, name, solves_per_launch):
         wr = c["WRITE_SIZE"] * 1024
         res["hbm_bytes_per_launch"] = {"read_corrected": rd, "write": wr, "total": rd + wr,
                                        "raw_fetch_kib": c["FETCH_SIZE"], "raw_write_kib": c["WRITE_SIZE"]}
+        tj = {"hbm_bytes_per_launch": rd + wr, "problems_per_launch": n // iterations,
+              "kernel_source_sha256": res["kernel_source_sha256"], "source": f"profiles/{name}.json",
+              "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1`; "
+                      "FETCH_SIZE doubled per the gfx950 correction; per launch of fused_iterate_kernel<10> over "
+                      f"{n // iterations} problems x {iterations} iterations"}
+        if "executed_fp64_flop_per_solve" in res:
+            tj["executed_flop_per_solve"] = res["executed_fp64_flop_per_solve"]
         with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
-            json.dump({"hbm_bytes_per_launch": rd + wr, "source": f"profiles/{name}.json",
-                       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); FETCH_SIZE doubled "
-                               "per the gfx950 correction; per launch of fused_iterate_kernel<10> over "
-                               f"{n} solves"}, f, indent=1)
+            json.dump(tj, f, indent=1)
+    # second trace: every workload of the bench, each kernel with what its code object carries
+    allk = []
+    stats_all = glob.glob(os.path.join(src, "kt_all", "**", "*_kernel_stats.csv"), recursive=True)
+    if stats_all:
+        for r in list(csv.DictReader(open(stats_all[0])))[:14]:
+            nm = short(r["Name"])
+            m = meta.get(nm, {})
+            allk.append({"kernel": nm, "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                         "percent": float(r["Percentage"]), "vgpr": m.get("vgpr_count"), "agpr": m.get("agpr_count"),
+                         "vgpr_spills": m.get("vgpr_spill_count"), "scratch_bytes_per_lane": m.get("private_segment_fixed_size"),
+                         "static_lds": m.get("group_segment_fixed_size")})
+        res["all_workloads_kernels"] = allk
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     with open(os.path.join(ROOT, "profiles", name + ".json"), "w") as f:
         json.dump(res, f, indent=1)
     with open(os.path.join(ROOT, "profiles", name + ".md"), "w") as f:
         f.write(f"# {name}: rocprofv3 summary of `python bench.py --steps 3 --warmup 1` (1 x MI355X)\n\n")
         f.write("## --kernel-trace --stats\n\n" + "\n".join(lines) + "\n\n")
-        f.write("## dispatch\n\n" + json.dumps(res["dispatch"]) + "\n\n")
+        f.write("## dispatch (as recorded by the profiler)\n\n" + json.dumps(res["dispatch"]) + "\n\n")
+        f.write("## code object (build/obj, llvm-readelf --notes)\n\n"
+                + code_object_meta.table(res["code_object"]) + "\n\n")
         f.write("## PMC (separate passes), mean per launch of the iterate kernel\n\n")
         for k, v in sorted(res["counters_per_launch"].items()):
             f.write(f"- {k}: {v:.6g}\n")
@@ -79,8 +117,14 @@ def main(tag, name, solves_per_launch):
                   "hbm_bytes_per_launch"):
             if k in res:
                 f.write(f"- {k}: {json.dumps(res[k])}\n")
+        if allk:
+            f.write("\n## all bench workloads (`bench.py --steps 3 --warmup 1 --no-cpu-baseline`), --kernel-trace --stats\n\n")
+            f.write("| kernel | calls | avg ns | total % | vgpr | agpr | vgpr spills | scratch B/lane | static LDS B |\n|---|---|---|---|---|---|---|---|---|\n")
+            for k in allk:
+                f.write(f"| {k['kernel'][:80]} | {k['calls']} | {k['avg_ns']:.0f} | {k['percent']} | {k['vgpr']} | {k['agpr']} | "
+                        f"{k['vgpr_spills']} | {k['scratch_bytes_per_lane']} | {k['static_lds']} |\n")
     print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 131072 * 50)
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else (1 << 20) * 50)

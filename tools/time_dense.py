@@ -1,37 +1,43 @@
-"""Tuning helper: time the wave-per-problem kernels on config-4 style workloads."""
+"""Timing of the wave-per-problem kernel on benchmark config 4 (staging off), with and without
+the collision limit; MINK_AMD_LIB selects a tuning build of the library."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+os.environ["MK_NO_STAGED"] = "1"
 import torch
 from mink_amd import workloads as W
 from mink_amd.engine import DeviceModel, DeviceProblem
 from mink_amd.mjcf import load_builtin
 
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 model = load_builtin("tidybot_cube")
-dm = DeviceModel(model, "cuda:0")
+dev = torch.device("cuda:0")
+dm = DeviceModel(model, dev)
 tasks, limits = W.config4_specs(model)
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-q, tg = W.config4_inputs(model, dm, B, 3)
-variants = {
-    "config4 (frame+rel+posture, cfg+vel+collision)": (tasks, limits, tg),
-    "no collision (frame+rel+posture, cfg+vel)": (tasks, limits[:2], tg),
-    "rel+posture, cfg+vel": (tasks[1:], limits[:2], tg[:, 7:].contiguous()),
-    "rel+posture, no limits": (tasks[1:], [], tg[:, 7:].contiguous()),
-    "collision only": ([], limits[2:], None),
-}
-for name, (t, l, targets) in variants.items():
-    prob = DeviceProblem(dm, t, l)
-    v = torch.empty((B, model.nv), dtype=torch.float64, device="cuda:0")
-    st = torch.empty(B, dtype=torch.int32, device="cuda:0")
-    for _ in range(2):
-        prob.solve(q, targets, W.DT, W.DAMPING, v=v, status=st)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    n = 4
-    for _ in range(n):
-        prob.solve(q, targets, W.DT, W.DAMPING, v=v, status=st)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+q, t = W.config4_inputs(model, dm, n, 7)
+
+
+def timed(f, reps=5):
+    f(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(n):
-        prob.build_qp(q[:16384].contiguous(), None if targets is None else targets[:16384].contiguous(), W.DT, W.DAMPING)
-    torch.cuda.synchronize(); db = (time.perf_counter() - t0) / n * (B / 16384)
-    print(f"{name:48s} fused={prob.fused} rows={prob.n_rows:3d} solve {dt*1e3:8.3f} ms ({B/dt/1e6:7.2f} M/s)  "
-          f"build-only ~{db*1e3:8.3f} ms  bad={int((st != 0).sum())}", flush=True)
+    for _ in range(reps):
+        f()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / reps
+
+
+out = [os.path.basename(os.environ.get("MINK_AMD_LIB", "default"))]
+for name, lim in (("coll", limits), ("nocoll", limits[:-1])):
+    p = DeviceProblem(dm, tasks, lim)
+    v = torch.empty((n, p.nv), dtype=torch.float64, device=dev)
+    s = torch.empty((n,), dtype=torch.int32, device=dev)
+    ts = timed(lambda: p.solve(q, t, W.DT, W.DAMPING, v, s))
+    out.append(f"{name}: {ts:.3f} ms ({ts*1e6/n:.1f} ns/problem)")
+near = int(n * 0.25)
+p = DeviceProblem(dm, tasks, limits)
+for name, sl in (("near", slice(0, near)), ("far", slice(near, n))):
+    qq, tt = q[sl].contiguous(), t[sl].contiguous()
+    m = qq.shape[0]
+    v = torch.empty((m, p.nv), dtype=torch.float64, device=dev)
+    s = torch.empty((m,), dtype=torch.int32, device=dev)
+    ts = timed(lambda: p.solve(qq, tt, W.DT, W.DAMPING, v, s))
+    out.append(f"{name}: {ts*1e6/m:.1f} ns/problem")
+print(" | ".join(out))
