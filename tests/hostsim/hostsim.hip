@@ -186,6 +186,24 @@ extern "C" int hostsim_solve_rows(const mk_model_desc* md, const mk_task_desc* t
   HS_DISPATCH(run_rows, D, X, q, targets, stride, dt, damping, B, v, good, nrows)
 }
 
+// box_box_lane on B box pairs: c [B,3], quaternion [B,4] (wxyz), half sizes [B,3] per box;
+// out [B,8] = (in range, dist, p1, p2).
+extern "C" void hostsim_box_box(const double* c1, const double* q1, const double* h1, const double* c2, const double* q2,
+                                const double* h2, int B, double distmax, double* out) {
+  for (int b = 0; b < B; ++b) {
+    const double *a = q1 + 4 * b, *e = q2 + 4 * b;
+    Contact ct;
+    ct.dist = 0.0;
+    ct.p1 = ct.p2 = v3(0, 0, 0);
+    const bool in = box_box_lane(v3(c1[3 * b], c1[3 * b + 1], c1[3 * b + 2]), q2m(Q4{a[0], a[1], a[2], a[3]}),
+                                 v3(h1[3 * b], h1[3 * b + 1], h1[3 * b + 2]), v3(c2[3 * b], c2[3 * b + 1], c2[3 * b + 2]),
+                                 q2m(Q4{e[0], e[1], e[2], e[3]}), v3(h2[3 * b], h2[3 * b + 1], h2[3 * b + 2]), distmax, ct);
+    double* o = out + 8 * b;
+    o[0] = in ? 1.0 : 0.0; o[1] = ct.dist;
+    o[2] = ct.p1.x; o[3] = ct.p1.y; o[4] = ct.p1.z; o[5] = ct.p2.x; o[6] = ct.p2.y; o[7] = ct.p2.z;
+  }
+}
+
 // The device waypoint generator on B (current pose, goal pose) pairs (wxyz_xyz each):
 // commanded poses [B, 7] and reached flags [B].
 extern "C" void hostsim_waypoint_step(const double* cur, const double* goal, int B, double pos_thr, double pos_step,

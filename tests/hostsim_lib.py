@@ -102,3 +102,13 @@ def solve_rows(model, task_specs, limit_specs, q, targets, dt, damping):
     if rc != 0:
         raise RuntimeError(f"hostsim rc={rc}: {h.mk_last_error().decode()}")
     return v, good, nrows
+
+
+def box_box(c1, q1, h1, c2, q2, h2, distmax):
+    """The device's one-lane box-box distance on B pairs: (in range [B], dist [B], p1 [B,3], p2 [B,3])."""
+    h = _load()
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (c1, q1, h1, c2, q2, h2)]
+    B = arrs[0].shape[0]
+    out = np.zeros((B, 8))
+    h.hostsim_box_box(*[_ptr(a) for a in arrs], C.c_int(B), C.c_double(distmax), _ptr(out))
+    return out[:, 0] > 0, out[:, 1], out[:, 2:5], out[:, 5:8]
