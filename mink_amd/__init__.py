@@ -10,7 +10,7 @@ from .constants import (FRAME_TO_ENUM, FRAME_TO_JAC_FUNC, FRAME_TO_POS_ATTR, FRA
 from .exceptions import (InvalidDamping, InvalidFrame, InvalidGain, InvalidKeyframe, InvalidMocapBody, InvalidTarget,
                          LimitDefinitionError, MinkError, NotWithinConfigurationLimits, TargetNotSet,
                          TaskDefinitionError, UnsupportedFrame)
-from .mjcf import Model, load_builtin, load_mjcf
+from .mjcf import Model, load_builtin, load_mjcf, load_mjcf_string
 
 _GPU_NAMES = {
     "Configuration": "configuration", "SE3": "lie", "SO3": "lie", "MatrixLieGroup": "lie",
@@ -46,4 +46,4 @@ __all__ = tuple(_GPU_NAMES) + (
     "MinkError", "UnsupportedFrame", "InvalidFrame", "InvalidKeyframe", "NotWithinConfigurationLimits",
     "TargetNotSet", "InvalidMocapBody", "InvalidTarget", "InvalidGain", "InvalidDamping", "TaskDefinitionError",
     "LimitDefinitionError", "SUPPORTED_FRAMES", "FRAME_TO_ENUM", "FRAME_TO_JAC_FUNC", "FRAME_TO_POS_ATTR",
-    "FRAME_TO_XMAT_ATTR", "Model", "load_mjcf", "load_builtin")
+    "FRAME_TO_XMAT_ATTR", "Model", "load_mjcf", "load_mjcf_string", "load_builtin")
