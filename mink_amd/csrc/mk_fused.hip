@@ -889,13 +889,25 @@ MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* 
   tip.t = tw - qrot(tip.q, v3(D->post_pos[0], D->post_pos[1], D->post_pos[2]));
   bool ok = true;
   const int np = X->ncpair;
+  // pose of the body walked last from the chain (consecutive pairs usually share it; the body
+  // index is the same for all lanes, so the test is a scalar branch)
+  int cached = -1;
+  PoseQT cpose = tip;
+  auto body_pose = [&](int b) -> PoseQT {
+    if (X->cbody[b].kind != MK_CB_TIP) return coll_body_pose(X, row, tip, b);
+    if (b != cached) {
+      cpose = coll_body_pose(X, row, tip, b);
+      cached = b;
+    }
+    return cpose;
+  };
   for (int k = 0; k < np; ++k) {
     const MkCollPair P = X->cpair[k];
     const MkCollGeom& G1 = X->cgeom[P.g1];
     const MkCollGeom& G2 = X->cgeom[P.g2];
-    const PoseQT a = pose_then(coll_body_pose(X, row, tip, G1.body), Q4{G1.lq[0], G1.lq[1], G1.lq[2], G1.lq[3]},
+    const PoseQT a = pose_then(body_pose(G1.body), Q4{G1.lq[0], G1.lq[1], G1.lq[2], G1.lq[3]},
                                v3(G1.lp[0], G1.lp[1], G1.lp[2]));
-    const PoseQT b = pose_then(coll_body_pose(X, row, tip, G2.body), Q4{G2.lq[0], G2.lq[1], G2.lq[2], G2.lq[3]},
+    const PoseQT b = pose_then(body_pose(G2.body), Q4{G2.lq[0], G2.lq[1], G2.lq[2], G2.lq[3]},
                                v3(G2.lp[0], G2.lp[1], G2.lp[2]));
     const M3 R1 = q2m(a.q);
     const V3 s2 = v3(G2.size[0], G2.size[1], G2.size[2]);
@@ -1114,6 +1126,7 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
 #pragma unroll
         for (int k = 0; k < M; ++k) best[k] = 0.0;
         for (int w = 0; w < (1 << M); ++w) {
+          if (mk_wave_none(!found && (w >> nrows) == 0)) continue;   // no lane of the wave needs this set
           if (found || (w >> nrows) != 0) continue;
           // rows outside the set: unit row / column, zero right-hand side
           double A[M][M], rhs[M];
