@@ -108,7 +108,12 @@ def main(tag, name, solves_per_launch, iterations=50):
         f.write("## --kernel-trace --stats\n\n" + "\n".join(lines) + "\n\n")
         f.write("## dispatch (as recorded by the profiler)\n\n" + json.dumps(res["dispatch"]) + "\n\n")
         f.write("## code object (build/obj, llvm-readelf --notes)\n\n"
-                + code_object_meta.table(res["code_object"]) + "\n\n")
+                + code_object_meta.table(res["code_object"]) + "\n\n"
+                "The profiler's dispatch line shows the architectural VGPR half only (granule-rounded) and no "
+                "dynamic LDS; the code object's vgpr_count is the unified total (architectural + AGPR), which is "
+                "what limits the kernel to one wave per SIMD. Dynamic LDS of the launch: 64 x ((nq | 1) + "
+                "NC (NC + 1) / 2) x 8 B = 44032 B per block for TidyBot (nq 31, NC 10); four blocks are resident "
+                "per CU (adding 4 KB per block drops the kernel to three and its time by 4/3, measured).\n\n")
         f.write("## PMC (separate passes), mean per launch of the iterate kernel\n\n")
         for k, v in sorted(res["counters_per_launch"].items()):
             f.write(f"- {k}: {v:.6g}\n")
