@@ -1068,11 +1068,11 @@ int mk_solve_ik_batch(const mk_problem* p, const double* d_q, const double* d_ta
     // both overwrite velocity and status of the problems they finish.
     MK_HIP(mk_fused_launch_step_ext(p->nc_kernel, p->d_fused, p->d_ext, p->info.nq, d_q, d_targets, p->info.target_stride,
                                     dt, damping, B, d_v, d_status, static_cast<hipStream_t>(stream)));
-    static const bool lane_rows = getenv("MK_NO_LANE_ROWS") == nullptr;   // tuning / tests: skip the middle stage
+    const bool lane_rows = getenv("MK_NO_LANE_ROWS") == nullptr;   // tuning / tests: skip the middle stage
     if (p->h_ext.ncpair > 0 && lane_rows)
       MK_HIP(mk_fused_launch_rows(p->nc_kernel, p->d_fused, p->d_ext, p->info.nv, d_q, d_targets, p->info.target_stride,
                                   dt, damping, B, d_v, d_status, static_cast<hipStream_t>(stream)));
-    static const bool general_stage = getenv("MK_NO_GENERAL_STAGE") == nullptr;   // tuning: leave the rest pending
+    const bool general_stage = getenv("MK_NO_GENERAL_STAGE") == nullptr;   // tuning / tests: leave the rest pending
     if (p->h_ext.ncpair > 0 && general_stage)
       MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets,
                              p->info.target_stride, dt, damping, B, nullptr, nullptr, nullptr, nullptr, d_v, d_status, -1,

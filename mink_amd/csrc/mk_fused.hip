@@ -973,19 +973,23 @@ MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* 
 // problem mu' >= 0, r(mu') <= 0, mu'.r(mu') = 0 of that piece exactly (enumeration of the 2^rows
 // active sets), then the box problem is solved again.  When the Karush-Kuhn-Tucker conditions
 // of the rows hold at a box solution, that solution is the optimum of the whole QP.  The iteration
-// visits pieces and normally ends in one to three steps; it is not guaranteed to (the caller
-// hands such a problem to the general kernel).
+// visits pieces and normally ends in one to three steps; a step that lands on another piece
+// without reducing the natural residual sum_k min(mu_k, -r_k)^2 is halved.  On a piece where every dof of a
+// violated row sits at a bound, S has a zero and the piece gives no step; the row's multiplier
+// then moves to the point where the first of those bounds lets go (a ratio test on the bound
+// multipliers).  Termination is not guaranteed: the caller hands a problem that does not finish
+// in kOuter steps to the general kernel.
 // Returns true with x (chain dofs) and the other dofs' dq in vrow[dof] (already divided by dt).
 template <int NC>
 MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView H, const double (&c)[NC],
                     const double (&lo)[NC], const double (&hi)[NC], double diag, double dt, double inv_dt,
                     const LaneRows& R, double (&x)[NC], double* vrow) {
   constexpr int M = MK_LANE_ROWS;
-  constexpr int kOuter = 8;
-  constexpr double kTol = 1e-12;
-  double mu[M];
+  constexpr int kOuter = 16;
+  constexpr double kTol = 1e-13;
+  double mu[M], mu_prev[M], merit_prev = INFINITY;
 #pragma unroll
-  for (int k = 0; k < M; ++k) mu[k] = 0.0;
+  for (int k = 0; k < M; ++k) mu[k] = mu_prev[k] = 0.0;
   uint32_t act = 0u, upper = 0u;
   bool done = false, good = false;
   const int nd = D->nd, nrows = R.n;
@@ -1051,12 +1055,26 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
         const double tol = kTol * fmax(1.0, fabs(R.h[k]));
         if (k < nrows) kkt &= (mu[k] > 0.0) ? (fabs(r[k]) <= tol) : (r[k] <= tol);
       }
+      // natural residual of the rows' complementarity conditions: the step control's merit
+      double merit = 0.0;
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        const double rho = fmin(mu[k], -r[k]);
+        if (k < nrows) merit += rho * rho;
+      }
       if (infeasible) {
         done = true;
       } else if (kkt) {
         done = true;
         good = true;
+      } else if (!(merit < merit_prev)) {
+        // the step left the piece it was computed on and did not help: halve it
+#pragma unroll
+        for (int k = 0; k < M; ++k) mu[k] = mu_prev[k] + 0.5 * (mu[k] - mu_prev[k]);
       } else {
+        merit_prev = merit;
+#pragma unroll
+        for (int k = 0; k < M; ++k) mu_prev[k] = mu[k];
         // ---- S on the current piece ----
         double L[NC * (NC + 1) / 2], Ld[NC];
         asm volatile("" ::: "memory");
@@ -1191,7 +1209,55 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
           }
         }
         if (!found) {
-          done = true;
+          // No step on this piece: a violated row whose dofs all sit at bounds has no curvature
+          // (S_kk = 0).  Its multiplier then grows until the first of those bounds lets go: with x
+          // fixed, the multiplier u_i of an active bound moves at the rate -+G_ki, a clamped dof's
+          // unconstrained value at the rate -G_kd / w_d (ratio test).  A little beyond that point
+          // the box problem frees the dof and the next piece has curvature.
+          asm volatile("" ::: "memory");
+          double hx[NC];
+          symv<NC>(H, x, hx);
+          int kstep = -1;
+          double worst = 0.0, tstep = 0.0;
+#pragma unroll
+          for (int k = 0; k < M; ++k) {
+            const double tol = kTol * fmax(1.0, fabs(R.h[k]));
+            double tau = INFINITY;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+              const int dof = D->seg_dof[i];
+              const double gki = dof >= 0 ? R.at(k, dof) : 0.0;
+              const bool up = (upper >> i) & 1u;
+              const double gi = cm[i] + hx[i];
+              const double ui = fmax(up ? -gi : gi, 0.0), slope = up ? -gki : gki;
+              if (((act >> i) & 1u) && slope < 0.0) tau = fmin(tau, ui / -slope);
+            }
+            for (int d = 0; d < nd; ++d) {
+              const MkDofC dc = D->ddof[d];
+              const double qi = row[dc.qadr];
+              const double vb = dt * dc.vmax;
+              const double h = fmin(dc.gain * (dc.upper - qi), vb);
+              const double l = fmax(-(dc.gain * (qi - dc.lower)), -vb);
+              double sft = 0.0;
+#pragma unroll
+              for (int kk = 0; kk < M; ++kk) sft += mu[kk] * R.at(kk, dc.dof);
+              const double w = diag + dc.W, gkd = R.at(k, dc.dof);
+              const double raw = -(dc.B * qi - dc.A + sft) / w;
+              if (raw > h && gkd > 0.0) tau = fmin(tau, (raw - h) * w / gkd);
+              if (raw < l && gkd < 0.0) tau = fmin(tau, (l - raw) * w / -gkd);
+            }
+            // the most violated row moves (one at a time: the others' ratio tests assume x fixed)
+            if (k < nrows && r[k] > tol && tau < INFINITY && r[k] > worst) {
+              worst = r[k];
+              kstep = k;
+              tstep = tau;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < M; ++k)
+            if (k == kstep) mu[k] += tstep * (1.0 + 1e-6) + 1e-14;
+          merit_prev = INFINITY;   // a step of this kind is taken as it is
+          if (kstep < 0) done = true;
         } else {
 #pragma unroll
           for (int k = 0; k < M; ++k) mu[k] = best[k];
