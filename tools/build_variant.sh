@@ -16,7 +16,7 @@ for f in mk_generic mk_dense mk_lie mk_api; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c mink_amd/csrc/$f.hip -o build_ab/$f.o &
   fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "${fflags[@]}" -c mink_amd/csrc/mk_fused.hip -o build_ab/fused_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-sched-strategy=max-ilp "${fflags[@]}" -c mink_amd/csrc/mk_fused.hip -o build_ab/fused_$name.o
 wait
 dobj=build_ab/mk_dense.o; [ ${#dflags[@]} -gt 0 ] && dobj=build_ab/dense_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared build_ab/fused_$name.o build_ab/mk_generic.o $dobj build_ab/mk_lie.o build_ab/mk_api.o -o build_ab/libmink_$name.so
