@@ -130,10 +130,11 @@ typedef struct mk_problem_info {
   int32_t n_rows;        /* rows of the stacked inequality matrix G (mink/solve_ik.py:40) */
   int32_t fused;         /* 1: the single-kernel structured path serves this problem */
   int32_t n_chain;       /* dofs with dense coupling in the fused path */
-  int32_t staged;        /* 1: mk_solve_ik_batch runs the structured kernel on every problem and the
-                            general kernel only on those with a collision pair within its detection
-                            distance (one frame task, optionally a relative frame task on the same
-                            frame, posture tasks, any limits) */
+  int32_t staged;        /* 1: mk_solve_ik_batch runs the structured kernel on every problem, a
+                            lane-per-problem kernel with the collision rows on those with a geom pair
+                            that may be within its detection distance, and the general kernel on what
+                            that one leaves (one frame task, optionally a relative frame task on the
+                            same frame, posture tasks, any limits) */
 } mk_problem_info;
 
 /* Replaces mujoco.MjModel.from_xml_path + mujoco.MjData construction
@@ -150,6 +151,14 @@ int mk_problem_create(const mk_model* model, const mk_task_desc* tasks, int32_t 
                       const mk_limit_desc* limits, int32_t nlimit, mk_problem** out);
 void mk_problem_destroy(mk_problem* problem);
 int mk_problem_get_info(const mk_problem* problem, mk_problem_info* info);
+
+/* PostureTask.set_target / set_target_from_configuration (mink/tasks/posture_task.py:62-85)
+ * on an existing problem: replaces the target of posture task number `task` (index into the
+ * task list given to mk_problem_create) by target_q [nq] (host memory), without rebuilding the
+ * problem.  The update is ordered on `stream` like a launch: solves queued before it see the
+ * old target, solves queued after it the new one; it must not run concurrently with solves
+ * of the same problem on other streams. */
+int mk_problem_set_posture_target(mk_problem* problem, int32_t task, const double* target_q, void* stream);
 
 /* mink.solve_ik without the limit check (mink/solve_ik.py:100-105): build the QP
  * of every problem, solve it exactly and return v = dq / dt.

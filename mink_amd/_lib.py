@@ -164,6 +164,7 @@ _SIGNATURES = {
                                     C.POINTER(C.c_void_p)]),
     "mk_problem_destroy": (None, [C.c_void_p]),
     "mk_problem_get_info": (C.c_int, [C.c_void_p, C.POINTER(ProblemInfo)]),
+    "mk_problem_set_posture_target": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mk_solve_ik_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "mk_solve_ik_iterate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int32,

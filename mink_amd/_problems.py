@@ -45,4 +45,8 @@ def get_problem(configuration, tasks: Sequence, limits: Sequence):
         limit_specs = [s for s in (l._spec(model) for l in limits) if s is not None]
         prob = DeviceProblem(configuration.dmodel, task_specs, limit_specs)
         cache[key] = prob
+    # posture targets are not part of the key: bring the problem's copies up to date
+    for i, t in enumerate(tasks):
+        if hasattr(t, "_posture_target"):
+            prob.set_posture_target(i, t._posture_target())
     return prob, targets

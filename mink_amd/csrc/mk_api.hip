@@ -138,6 +138,7 @@ struct mk_problem {
   MkDenseProblem h_dense;
   MkDenseProblem* d_dense;
   std::vector<int> task_k;  // error dimension of each task
+  std::vector<int> task_type;
   std::vector<void*> allocs;
 };
 
@@ -971,6 +972,7 @@ int mk_problem_create(const mk_model* model, const mk_task_desc* tasks, int32_t 
   }
   mk_problem* p = new mk_problem();
   p->model = model;
+  for (int t = 0; t < ntask; ++t) p->task_type.push_back(tasks[t].type);
   p->d_fused = nullptr;
   p->d_dense = nullptr;
   p->info.nq = m.nq;
@@ -1049,6 +1051,40 @@ void mk_problem_destroy(mk_problem* p) {
 int mk_problem_get_info(const mk_problem* p, mk_problem_info* info) {
   if (!p || !info) return fail(MK_ERR_INVALID, "null argument");
   *info = p->info;
+  return MK_OK;
+}
+
+int mk_problem_set_posture_target(mk_problem* p, int32_t task, const double* target_q, void* stream) {
+  if (!p || !target_q) return fail(MK_ERR_INVALID, "null argument");
+  if (task < 0 || task >= (int)p->task_type.size() || p->task_type[task] != MK_TASK_POSTURE)
+    return fail(MK_ERR_INVALID, "task %d is not a posture task of this problem", task);
+  MK_ON_DEVICE(p->model);
+  const HostModel& m = p->model->h;
+  for (int i = 0; i < m.nq; ++i)
+    if (!(std::fabs(target_q[i]) < INFINITY)) return fail(MK_ERR_INVALID, "posture target is not finite");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (p->fused || p->staged) {
+    // the k-th posture task of the list is posture[k]; its target enters the per-dof constant
+    // A = sum_t gain_t cost_t^2 target_t of the chain slots and of the other scalar dofs
+    int k = 0;
+    for (int t = 0; t < task; ++t) k += p->task_type[t] == MK_TASK_POSTURE;
+    MkFusedDesc& D = p->h_fused;
+    MkPosture& P = D.posture[k];
+    for (int i = 0; i < m.nv; ++i)
+      if (D.dof[i].kind == MK_DOF_SCALAR) P.target[i] = target_q[D.dof[i].qadr];
+    auto refresh = [&](MkDofC& c) {
+      if (c.dof < 0) return;
+      c.A = 0.0;
+      for (int t = 0; t < D.nposture; ++t)
+        c.A += D.posture[t].gain * D.posture[t].cost[c.dof] * D.posture[t].cost[c.dof] * D.posture[t].target[c.dof];
+    };
+    for (int s = 0; s < MK_MAX_CHAIN; ++s) refresh(D.sdof[s]);
+    for (int d = 0; d < D.nd; ++d) refresh(D.ddof[d]);
+    MK_HIP(hipMemcpyAsync(p->d_fused, &p->h_fused, sizeof(MkFusedDesc), hipMemcpyHostToDevice, st));
+  }
+  if (p->dense)
+    MK_HIP(hipMemcpyAsync(const_cast<double*>(p->h_dense.task[task].ptarget), target_q, sizeof(double) * m.nq,
+                          hipMemcpyHostToDevice, st));
   return MK_OK;
 }
 

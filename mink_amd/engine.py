@@ -105,6 +105,23 @@ class DeviceProblem:
         self.fused = bool(info.fused)
         self.n_chain = info.n_chain
         self.staged = bool(info.staged)
+        # posture targets the device copies currently hold, by task index
+        self._posture_targets = {i: np.ascontiguousarray(s["target_q"], dtype=np.float64).tobytes()
+                                 for i, s in enumerate(task_specs) if s["type"] == L.TASK_POSTURE}
+
+    def set_posture_target(self, task_index: int, target_q: np.ndarray) -> None:
+        """New target of posture task `task_index` (mk_problem_set_posture_target), ordered on the
+        current stream; a no-op when the device copy already holds it."""
+        target_q = np.ascontiguousarray(target_q, dtype=np.float64)
+        raw = target_q.tobytes()
+        if self._posture_targets.get(task_index) == raw:
+            return
+        if target_q.shape != (self.nq,):
+            raise ValueError(f"posture target must have shape ({self.nq},)")
+        with torch.cuda.device(self.device):
+            L.check(self.lib.mk_problem_set_posture_target(self.handle, int(task_index),
+                                                           target_q.ctypes.data_as(C.c_void_p), _stream_ptr(self.device)))
+        self._posture_targets[task_index] = raw
 
     def __del__(self):
         h = getattr(self, "handle", None)

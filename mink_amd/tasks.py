@@ -302,8 +302,12 @@ class PostureTask(Task):
     def _key(self, model):
         if self.target_q is None:
             raise TargetNotSet(self.__class__.__name__)
-        return (L.TASK_POSTURE, self.cost.tobytes(), np.asarray(self.target_q, dtype=np.float64).tobytes(),
-                self.gain, self.lm_damping)
+        # the target is per-call data of the device problem (mk_problem_set_posture_target): a task
+        # whose target changes every tick keeps its problem
+        return (L.TASK_POSTURE, self.cost.tobytes(), self.gain, self.lm_damping)
+
+    def _posture_target(self) -> np.ndarray:
+        return np.ascontiguousarray(self.target_q, dtype=np.float64)
 
     def _spec(self, model) -> dict:
         if self.target_q is None:

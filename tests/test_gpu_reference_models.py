@@ -123,3 +123,39 @@ def test_zero_damping_on_a_dof_without_cost_is_reported():
     v = mink.solve_ik(cfg, [task], 0.005, "quadprog", 1e-12, limits=[])
     cfg.check()
     assert float(v.abs().max()) <= 1e-9
+
+
+def test_posture_target_update_keeps_the_problem():
+    """A PostureTask whose target changes from call to call (PostureTask.set_target,
+    mink/tasks/posture_task.py:62-85) reuses its device problem: the target is updated in place,
+    on the fused and on the general path, and the answers follow it."""
+    from mink_amd.mjcf import load_builtin
+    model = load_builtin("tidybot_cube")
+    rng = np.random.default_rng(4)
+    from mink_amd import workloads as W
+    q = W.sample_q(model, rng, 4)
+    for extra in ([], [mink.ComTask(cost=0.1)]):      # fused path / general path
+        cfg = mink.Configuration(model, q)
+        ftask = mink.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0)
+        ftask.set_target_from_configuration(cfg)
+        ptask = mink.PostureTask(model, cost=W.posture_cost(model))
+        for t in extra:
+            t.set_target_from_configuration(cfg)
+        n_before = None
+        for trial in range(3):
+            target = W.sample_q(model, rng, 1)[0]
+            ptask.set_target(target)
+            v = mink.solve_ik(cfg, [ftask, ptask] + extra, 0.005, "quadprog", 1e-3).cpu().numpy()
+            cfg.check()
+            n_now = len(cfg.dmodel.problem_cache)
+            assert n_before is None or n_now == n_before, "a changed posture target must not create a new problem"
+            n_before = n_now
+            for b in range(q.shape[0]):
+                ocfg = o.Configuration(model, q[b])
+                ot = [o.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0,
+                                  target=ocfg.get_transform_frame_to_world("pinch_site", "site")),
+                      o.PostureTask(cost=W.posture_cost(model), target_q=target)]
+                if extra:
+                    ot.append(o.ComTask(cost=np.full(3, 0.1), target_com=np.asarray(extra[0].target_com).reshape(-1, 3)[b]))
+                vr = o.solve_ik(ocfg, ot, 0.005, damping=1e-3, limits=[o.ConfigurationLimit(model)])
+                np.testing.assert_allclose(v[b], vr, rtol=0, atol=1e-8)
