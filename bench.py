@@ -332,7 +332,26 @@ def other_workloads(model, dm, prob, q0, targets, out, device, barrier):
     extra["config4_B262144_collision_relative_frame"] = {
         "solves_per_s": B4 * 3 / w4, "ms_per_launch": 1e3 * e4 / 3,
         "status_nonzero": int((s4 != 0).sum().item())}
-    del q4, tg4, v4, s4
+    # the callers' loop on the same problem (20 passes, no exit test): passes of the staged kernels, and the
+    # same loop as passes of the general kernel alone
+    Bl = 65536
+    out4 = dict(iters=torch.empty(Bl, dtype=torch.int32, device=device), err=torch.empty((Bl, 6), dtype=torch.float64, device=device),
+                status=torch.empty(Bl, dtype=torch.int32, device=device), v=torch.empty((Bl, model.nv), dtype=torch.float64, device=device))
+    ql = [q4[:Bl].clone() for _ in range(3)]
+    tl = tg4[:Bl].contiguous()
+    wl, el = time_launches(lambda i: p4.iterate_(ql[i], tl, W.DT, W.DAMPING, 20, -1.0, -1.0, out=out4), 2, 1, barrier)
+    loop4 = {"staged_passes": {"solves_per_s": Bl * 20 * 2 / wl, "ms_per_loop": 1e3 * el / 2},
+             "status_nonzero": int((out4["status"] != 0).sum().item())}
+    os.environ["MK_NO_STAGED_LOOP"] = "1"
+    try:
+        qg = [q4[:Bl].clone() for _ in range(2)]
+        wg, eg = time_launches(lambda i: p4.iterate_(qg[i], tl, W.DT, W.DAMPING, 20, -1.0, -1.0, out=out4), 1, 1, barrier)
+    finally:
+        del os.environ["MK_NO_STAGED_LOOP"]
+    loop4["general_kernel_passes"] = {"solves_per_s": Bl * 20 / wg, "ms_per_loop": 1e3 * eg}
+    loop4["max_abs_q_diff"] = float((ql[2] - qg[1]).abs().max().item())
+    extra["config4_loop_B65536_x20"] = loop4
+    del q4, tg4, v4, s4, ql, qg
     # kinematic move_to rollouts (waypoint generator + the callers' IK loop per waypoint step) as one launch
     import mink_amd as mk
     ftask = mk.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0)

@@ -22,7 +22,9 @@ hipError_t mk_fused_launch_step(int nc, const MkFusedDesc* d_desc, int nq, const
                                 hipStream_t stream);
 hipError_t mk_fused_launch_step_ext(int nc, const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nq, const double* q,
                                     const double* targets, int target_stride, double dt, double damping, int B,
-                                    double* v, int32_t* status, hipStream_t stream);
+                                    double* v, int32_t* status, hipStream_t stream, int32_t* iters = nullptr,
+                                    double* err = nullptr, int it = 0, int max_iters = 0, double pos_tol = 0.0,
+                                    double ori_tol = 0.0);
 hipError_t mk_fused_launch_rows(int nc, const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nv, const double* q,
                                 const double* targets, int target_stride, double dt, double damping, int B, double* v,
                                 int32_t* status, hipStream_t stream);
@@ -1135,6 +1137,35 @@ int mk_solve_ik_iterate_batch(const mk_problem* p, double* d_q, const double* d_
   MK_ON_DEVICE(p->model);
   if (!d_q || !d_status) return fail(MK_ERR_INVALID, "null argument");
   if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
+  if (p->staged && !getenv("MK_NO_STAGED_LOOP")) {
+    // Staged problems: one pass of the loop = the structured kernel in its loop mode (error, exit
+    // test and bookkeeping of the pass, then the solve of the problems still in the loop), the
+    // rows stage and the general kernel for what is pending, and the integration.  The optional
+    // outputs hold the state of the loop, as on the general path below.
+    if (!d_v || !d_iters || !d_err)
+      return fail(MK_ERR_INVALID, "outside the fused path d_v, d_iters and d_err hold the state of the loop and must be given");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nv = p->info.nv;
+    MK_HIP(hipMemsetAsync(d_iters, 0, sizeof(int32_t) * (size_t)B, st));
+    MK_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * (size_t)B, st));
+    MK_HIP(hipMemsetAsync(d_v, 0, sizeof(double) * (size_t)B * nv, st));
+    MK_HIP(hipMemsetAsync(d_err, 0, sizeof(double) * (size_t)B * 6, st));
+    for (int it = 0; it <= max_iters; ++it) {
+      MK_HIP(mk_fused_launch_step_ext(p->nc_kernel, p->d_fused, p->d_ext, p->info.nq, d_q, d_targets, p->info.target_stride,
+                                      dt, damping, B, d_v, d_status, st, d_iters, d_err, it, max_iters, pos_tol, ori_tol));
+      if (it == max_iters) break;
+      if (p->h_ext.ncpair > 0) {
+        MK_HIP(mk_fused_launch_rows(p->nc_kernel, p->d_fused, p->d_ext, p->info.nv, d_q, d_targets, p->info.target_stride, dt,
+                                    damping, B, d_v, d_status, st));
+        MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets,
+                               p->info.target_stride, dt, damping, B, nullptr, nullptr, nullptr, nullptr, d_v, d_status, -1,
+                               nullptr, nullptr, st, nullptr, true, true));
+      }
+      MK_HIP(mk_generic_integrate(p->model->dev, d_q, d_v, dt, B, st, d_iters));
+    }
+    MK_HIP(mk_generic_iterate_finish(d_iters, B, st));
+    return MK_OK;
+  }
   if (!p->fused) {
     // General path: the same loop as a sequence of launches of the wave-per-problem kernels.
     // The optional outputs double as the loop's state (no device memory is allocated):

@@ -1260,7 +1260,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MK_DENSE_WPE
         x = 0.0;
       }
       if (own) v_out[b * n + lane] = x / dt;
-      if (lane == 0) status_out[b] = accumulate_status ? max(status_out[b], st) : st;
+      if (lane == 0) status_out[b] = accumulate_status ? max(status_out[b] & ~MK_STATUS_PENDING, st) : st;
     }
     __syncthreads();
   }

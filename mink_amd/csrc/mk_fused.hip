@@ -1360,7 +1360,7 @@ __global__ MK_KERNEL_ATTR void fused_rows_kernel(const MkFusedDesc* __restrict__
       // lanes without a problem of their own repeat the first one, stores included (same values)
       const bool good = rows_problem<NC>(D, X, q + pb * nq, targets + pb * target_stride, dt, inv_dt, damping,
                                          v_out + pb * nv, hlds, 64, glds, 64);
-      if (valid && good) status_out[pb] = 0;
+      if (valid && good) status_out[pb] &= ~MK_STATUS_PENDING;   // the low bits: status accumulated by a loop
       const int rest = n - take;
       const int32_t mv = lane < rest ? queue[64 + lane] : 0;
       __syncthreads();
@@ -1374,14 +1374,23 @@ __global__ MK_KERNEL_ATTR void fused_rows_kernel(const MkFusedDesc* __restrict__
 
 // fused_step_kernel with the extension descriptor: an optional RelativeFrameTask term and the
 // collision screen.  A problem with a collision pair in range gets MK_STATUS_PENDING in its
-// status entry (its velocity row is then provisional) and is solved by the general kernel.
+// status entry (its velocity row is then provisional) and is solved by the later stages.
+//
+// With `iters` given the launch is one pass of the callers' loop (teleop_mouse.py:105-121) for
+// problems outside the one-launch path: it first does the loop's bookkeeping for pass `it` --
+// frame-task error of the current q to err_out, exit test (from the second pass on), solve count
+// or done bit to iters -- and then solves only the problems still in the loop, leaving velocity
+// and status of the others as they are; status accumulates (maximum over the passes) in its low
+// bits next to the pending bit.
 template <int NC>
 __global__ MK_KERNEL_ATTR void fused_step_ext_kernel(const MkFusedDesc* __restrict__ D,
                                                      const MkFusedExt* __restrict__ X,
                                                      const double* __restrict__ q,
                                                      const double* __restrict__ targets, int target_stride,
                                                      double dt, double damping, int B,
-                                                     double* __restrict__ v_out, int32_t* __restrict__ status_out) {
+                                                     double* v_out, int32_t* status_out, int32_t* iters,
+                                                     double* __restrict__ err_out, int it, int max_iters,
+                                                     double pos_tol, double ori_tol) {
   extern __shared__ double tile[];
   const int nq = D->nq, nv = D->nv;
   const int stride = nq | 1;
@@ -1409,6 +1418,20 @@ __global__ MK_KERNEL_ATTR void fused_step_ext_kernel(const MkFusedDesc* __restri
   M3 Rw;
   chain_jac_pose<NC, true>(D, qc, cj, Qw, tw, Rw, X->has_rel ? X->rel_slot : NC, &Qcap, &tcap);
   cj.e = frame_error(Qw, tw, Rw, Qt, pt);
+  bool skip = false;
+  if (iters) {
+    const int32_t cur = iters[pb];
+    const bool was_done = (cur & MK_ITER_DONE_BIT) != 0;
+    const bool conv = it > 0 && sqrt(dot(cj.e.v, cj.e.v)) <= pos_tol && sqrt(dot(cj.e.w, cj.e.w)) <= ori_tol;
+    const bool done_now = conv || it == max_iters;
+    if (valid && !was_done) {
+      double* eo = err_out + pb * 6;
+      eo[0] = cj.e.v.x; eo[1] = cj.e.v.y; eo[2] = cj.e.v.z; eo[3] = cj.e.w.x; eo[4] = cj.e.w.y; eo[5] = cj.e.w.z;
+      iters[pb] = done_now ? (cur | MK_ITER_DONE_BIT) : it + 1;
+    }
+    skip = was_done || done_now;
+    if (mk_wave_none(valid && !skip)) return;   // every problem of the block has left the loop
+  }
   bool bad = rest_nonfinite(D, row);
   // collision screen first: it reads the lane's q, which the solve consumes
   const bool pending = X->ncpair > 0 && collision_in_range(D, X, row, Qw, tw);
@@ -1434,7 +1457,17 @@ __global__ MK_KERNEL_ATTR void fused_step_ext_kernel(const MkFusedDesc* __restri
 #pragma unroll
   for (int k = 0; k < NC; ++k)
     if (D->seg_dof[k] >= 0) row[D->seg_dof[k]] = x[k] * inv_dt;
-  if (valid) status_out[pb] = (pending && status != 3) ? MK_STATUS_PENDING : status;
+  const int32_t flag = (pending && status != 3) ? MK_STATUS_PENDING : 0;
+  if (!iters) {
+    if (valid) status_out[pb] = flag ? flag : status;
+  } else if (valid) {
+    if (skip) {
+      // out of the loop: the tile copy below rewrites the velocity this problem already has
+      for (int i = 0; i < nv; ++i) row[i] = v_out[pb * nv + i];
+    } else {
+      status_out[pb] = max(status_out[pb] & ~MK_STATUS_PENDING, status) | flag;
+    }
+  }
   __syncthreads();
   tile_copy<false>(tile, stride, v_out + base * nv, rows, nv);
 }
@@ -1893,21 +1926,25 @@ hipError_t mk_fused_launch_step(int nc, const MkFusedDesc* d_desc, int nq, const
 template <int NC>
 static hipError_t launch_step_ext(const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nq, const double* q,
                                   const double* targets, int target_stride, double dt, double damping, int B, double* v,
-                                  int32_t* status, hipStream_t stream) {
+                                  int32_t* status, hipStream_t stream, int32_t* iters, double* err, int it,
+                                  int max_iters, double pos_tol, double ori_tol) {
   const int blocks = (B + 63) / 64;
   const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
   if (hipError_t e = allow_lds<fused_step_ext_kernel<NC>>(lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(fused_step_ext_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, d_ext, q, targets,
-                     target_stride, dt, damping, B, v, status);
+                     target_stride, dt, damping, B, v, status, iters, err, it, max_iters, pos_tol, ori_tol);
   return hipGetLastError();
 }
 
 hipError_t mk_fused_launch_step_ext(int nc, const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nq, const double* q,
                                     const double* targets, int target_stride, double dt, double damping, int B,
-                                    double* v, int32_t* status, hipStream_t stream) {
+                                    double* v, int32_t* status, hipStream_t stream, int32_t* iters, double* err, int it,
+                                    int max_iters, double pos_tol, double ori_tol) {
   switch (nc) {
-#define MK_CASE(N) \
-  case N: return launch_step_ext<N>(d_desc, d_ext, nq, q, targets, target_stride, dt, damping, B, v, status, stream);
+#define MK_CASE(N)                                                                                                  \
+  case N:                                                                                                           \
+    return launch_step_ext<N>(d_desc, d_ext, nq, q, targets, target_stride, dt, damping, B, v, status, stream, iters, \
+                              err, it, max_iters, pos_tol, ori_tol);
     MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
 #undef MK_CASE
     default: return hipErrorInvalidValue;

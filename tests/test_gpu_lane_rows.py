@@ -164,3 +164,45 @@ def test_lane_rows_rows_against_numpy_restatement(env):
         n_rows += int(np.isfinite(coll.inequalities(cfg, DT)[1]).sum())
         np.testing.assert_allclose(vn[i], vr, rtol=0, atol=1e-8, err_msg=f"problem {i}")
     assert n_rows >= 16
+
+
+@pytest.mark.parametrize("near", [False, True])
+def test_staged_loop_matches_general_loop(near):
+    """The callers' loop (teleop_mouse.py:105-121) for a problem with a RelativeFrameTask and a
+    CollisionAvoidanceLimit: passes of the staged kernels against passes of the general kernel."""
+    from mink_amd import workloads as W
+    from mink_amd.lie import SE3
+    from mink_amd.mjcf import load_builtin
+    model = load_builtin("tidybot_cube")
+    dm = DeviceModel(model, torch.device("cuda:0"))
+    tasks, limits = W.config4_specs(model)
+    B = 4096
+    q, tg = W.config4_inputs(model, dm, B, 11)
+    if near:   # targets a few millimetres from the current pose: most problems leave the loop early
+        site, base = model.site_id("pinch_site"), model.body_id("base_link")
+        cur = dm.frame_pose(q, L.FRAME_TYPES["site"], site)
+        g = torch.Generator(device="cpu").manual_seed(3)
+        xi = (torch.rand((B, 6), generator=g, dtype=torch.float64) - 0.5) * torch.tensor([0.01] * 3 + [0.03] * 3)
+        t_world = (SE3(cur) @ SE3.exp(xi.to(q.device))).wxyz_xyz
+        t_base = dm.frame_pose(q, L.FRAME_TYPES["body"], base)
+        tg = torch.cat([t_world, (SE3(t_base).inverse() @ SE3(t_world)).wxyz_xyz], dim=1).contiguous()
+    staged = DeviceProblem(dm, tasks, limits)
+    assert staged.staged
+    os.environ["MK_NO_STAGED"] = "1"
+    try:
+        general = DeviceProblem(dm, tasks, limits)
+    finally:
+        del os.environ["MK_NO_STAGED"]
+    qa, qb = q.clone(), q.clone()
+    ra = staged.iterate_(qa, tg, W.DT, W.DAMPING, 12, 1e-4, 1e-4, want_v=True)
+    rb = general.iterate_(qb, tg, W.DT, W.DAMPING, 12, 1e-4, 1e-4, want_v=True)
+    assert int(ra["status"].abs().sum()) == 0 and int(rb["status"].abs().sum()) == 0
+    same = ra["iters"] == rb["iters"]
+    print("near" if near else "far", "mean iterations", float(ra["iters"].double().mean()), "left early",
+          float((ra["iters"] < 12).double().mean()), "same count", float(same.double().mean()))
+    assert float(same.double().mean()) >= 0.999      # an exit test decided at 1e-4 +- rounding may differ
+    assert float((qa - qb)[same].abs().max()) <= 1e-8
+    assert float((ra["err"] - rb["err"])[same].abs().max()) <= 1e-8
+    assert float((ra["v"] - rb["v"])[same].abs().max()) <= 1e-7
+    if near:
+        assert float((ra["iters"] < 12).double().mean()) > 0.3
