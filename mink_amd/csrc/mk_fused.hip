@@ -1143,9 +1143,16 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
         double best[M];
 #pragma unroll
         for (int k = 0; k < M; ++k) best[k] = 0.0;
-        for (int w = 0; w < (1 << M); ++w) {
-          if (mk_wave_none(!found && (w >> nrows) == 0)) continue;   // no lane of the wave needs this set
-          if (found || (w >> nrows) != 0) continue;
+        // the sets are tried starting from the likely one -- the rows that carry a multiplier or are
+        // violated now -- so that most lanes are done after the first
+        int w0 = 0;
+#pragma unroll
+        for (int k = 0; k < M; ++k)
+          if (k < nrows && (mu[k] > 0.0 || r[k] > 0.0)) w0 |= 1 << k;
+        for (int trial = 0; trial < (1 << M); ++trial) {
+          if (mk_wave_none(!found && (trial >> nrows) == 0)) continue;   // no lane of the wave needs this set
+          if (found || (trial >> nrows) != 0) continue;
+          const int w = trial ^ w0;
           // rows outside the set: unit row / column, zero right-hand side
           double A[M][M], rhs[M];
 #pragma unroll
