@@ -74,7 +74,7 @@ def kernel_source_hash():
     for rel in KERNEL_SOURCES:
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
-    return h.hexdigest()[:16]
+    return h.hexdigest()
 
 
 def time_launches(fn, steps, warmup, barrier):
