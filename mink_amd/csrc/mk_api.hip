@@ -1102,7 +1102,7 @@ int mk_solve_ik_batch(const mk_problem* p, const double* d_q, const double* d_ta
     // Structured kernel for every problem; it marks the ones with a collision pair that may be
     // within its detection distance.  Those go through the lane-per-problem kernel that builds the
     // collision rows and solves the QP with them, and what that one leaves pending (more rows than
-    // it keeps, a pair type without a lane routine, no convergence) through the general kernel;
+    // it keeps, no convergence) through the general kernel;
     // both overwrite velocity and status of the problems they finish.
     MK_HIP(mk_fused_launch_step_ext(p->nc_kernel, p->d_fused, p->d_ext, p->info.nq, d_q, d_targets, p->info.target_stride,
                                     dt, damping, B, d_v, d_status, static_cast<hipStream_t>(stream)));

@@ -160,125 +160,30 @@ MK_GPU bool geom_distance(int lane, int t1, V3 c1, const M3& r1, V3 s1, int t2, 
   if (t1 == GEOM_PLANE && t2 == GEOM_BOX) {
     plane_box(c1, r1, c2, r2, s2, ct);
   } else if (t1 == GEOM_PLANE && t2 == GEOM_SPHERE) {
-    const V3 n = col(r1, 2);
-    ct.dist = dot(c2 - c1, n) - s2.x;
-    ct.p2 = c2 - s2.x * n;
-    ct.p1 = ct.p2 - ct.dist * n;
+    plane_sphere(c1, r1, c2, s2, ct);
   } else if (t1 == GEOM_SPHERE && t2 == GEOM_SPHERE) {
-    V3 d = c2 - c1;
-    double nrm = sqrt(dot(d, d));
-    V3 ax = nrm < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nrm) * d;
-    if (nrm < MK_MINVAL) nrm = 0.0;
-    ct.dist = nrm - s1.x - s2.x;
-    ct.p1 = c1 + s1.x * ax;
-    ct.p2 = c2 - s2.x * ax;
+    sphere_pair(c1, s1.x, c2, s2.x, ct);
   } else if (t1 == GEOM_PLANE && t2 == GEOM_CAPSULE) {
-    // the lower of the two end spheres (capsule: size = radius, half-length along its z axis)
-    const V3 n = col(r1, 2), ax = col(r2, 2);
-    const V3 ea = c2 + s2.y * ax, eb = c2 - s2.y * ax;
-    const double da = dot(ea - c1, n) - s2.x, db = dot(eb - c1, n) - s2.x;
-    const V3 e = da <= db ? ea : eb;
-    ct.dist = da <= db ? da : db;
-    ct.p2 = e - s2.x * n;
-    ct.p1 = ct.p2 - ct.dist * n;
+    plane_capsule(c1, r1, c2, r2, s2, ct);
   } else if ((t1 == GEOM_SPHERE || t1 == GEOM_CAPSULE) && t2 == GEOM_CAPSULE) {
-    // closest points of the axis segments (a sphere is a segment of length 0), then two spheres
-    const V3 a2 = col(r2, 2);
-    V3 u = c1, w;
-    if (t1 == GEOM_SPHERE) {
-      const double t = fmin(fmax(dot(c1 - c2, a2), -s2.y), s2.y);
-      w = c2 + t * a2;
-    } else {
-      const V3 a1 = col(r1, 2);
-      seg_seg(c1 - s1.y * a1, c1 + s1.y * a1, c2 - s2.y * a2, c2 + s2.y * a2, u, w);
-    }
-    V3 d = w - u;
-    double nrm = sqrt(dot(d, d));
-    V3 ax = nrm < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nrm) * d;
-    if (nrm < MK_MINVAL) nrm = 0.0;
-    ct.dist = nrm - s1.x - s2.x;
-    ct.p1 = u + s1.x * ax;
-    ct.p2 = w - s2.x * ax;
+    round_capsule(t1 == GEOM_CAPSULE, c1, r1, s1, c2, r2, s2, ct);
   } else if (t1 == GEOM_SPHERE && t2 == GEOM_BOX) {
-    const V3 loc = mulT(r2, c1 - c2);
-    const V3 cl = v3(fmin(fmax(loc.x, -s2.x), s2.x), fmin(fmax(loc.y, -s2.y), s2.y), fmin(fmax(loc.z, -s2.z), s2.z));
-    if (fabs(loc.x) > s2.x || fabs(loc.y) > s2.y || fabs(loc.z) > s2.z) {   // centre outside the box
-      const V3 pb = c2 + mul(r2, cl);
-      V3 d = c1 - pb;
-      double nrm = sqrt(dot(d, d));
-      V3 ax = nrm < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nrm) * d;
-      if (nrm < MK_MINVAL) nrm = 0.0;
-      ct.dist = nrm - s1.x;
-      ct.p1 = c1 - s1.x * ax;
-      ct.p2 = pb;
-    } else {   // centre inside: leave through the nearest face
-      const double gx = s2.x - fabs(loc.x), gy = s2.y - fabs(loc.y), gz = s2.z - fabs(loc.z);
-      const int k = (gx <= gy && gx <= gz) ? 0 : (gy <= gz ? 1 : 2);
-      const double lk = comp(loc, k), gk = k == 0 ? gx : (k == 1 ? gy : gz);
-      const double sgn = lk >= 0.0 ? 1.0 : -1.0;
-      const V3 ax = sgn * col(r2, k);
-      V3 face = loc;
-      if (k == 0) face.x = sgn * s2.x; else if (k == 1) face.y = sgn * s2.y; else face.z = sgn * s2.z;
-      ct.dist = -gk - s1.x;
-      ct.p2 = c2 + mul(r2, face);
-      ct.p1 = c1 - s1.x * ax;
-    }
+    sphere_box(c1, s1, c2, r2, s2, ct);
   } else if (t1 == GEOM_CAPSULE && t2 == GEOM_BOX) {
-    // Axis segment against the box: its two end points against the box (lanes 0, 1), the
-    // segment against the 12 box edges (lanes 2..13); first strict minimum in that numbering.
+    // Axis segment against the box: one candidate per lane, first strict minimum in their numbering.
     const V3 ax = col(r1, 2);
     const V3 a = c1 - s1.y * ax, b = c1 + s1.y * ax;
     double best = INFINITY;
     int bi = lane;
     V3 u = a, w = c2;
-    if (lane < 2) {
-      u = lane == 0 ? a : b;
-      w = box_closest(u, c2, r2, s2);
-      best = dot(u - w, u - w);
-    } else if (lane < 14) {
-      V3 b0, b1;
-      box_edge(c2, r2, s2, lane - 2, b0, b1);
-      seg_seg(a, b, b0, b1, u, w);
+    if (lane < MK_CAPSULE_BOX_CANDIDATES) {
+      capsule_box_candidate(lane, a, b, c2, r2, s2, u, w);
       best = dot(u - w, u - w);
     }
     wave_argmin(best, bi);
     u = bcast3(u, bi);
     w = bcast3(w, bi);
-    // a segment that passes through the box: the middle of the part inside leaves through
-    // its nearest face, like a sphere centre inside a box
-    const V3 la = mulT(r2, a - c2), ld = mulT(r2, b - a);
-    double t0 = 0.0, t1c = 1.0;
-    for (int k = 0; k < 3; ++k) {
-      const double lk = comp(la, k), dk = comp(ld, k), hk = comp(s2, k);
-      if (fabs(dk) < 1e-300) {
-        if (fabs(lk) > hk) { t0 = 1.0; t1c = 0.0; }
-      } else {
-        const double ta = (-hk - lk) / dk, tb = (hk - lk) / dk;
-        t0 = fmax(t0, fmin(ta, tb));
-        t1c = fmin(t1c, fmax(ta, tb));
-      }
-    }
-    if (t0 <= t1c) {
-      const V3 loc = la + (0.5 * (t0 + t1c)) * ld;
-      const double gx = s2.x - fabs(loc.x), gy = s2.y - fabs(loc.y), gz = s2.z - fabs(loc.z);
-      const int k = (gx <= gy && gx <= gz) ? 0 : (gy <= gz ? 1 : 2);
-      const double lk = comp(loc, k), gk = k == 0 ? gx : (k == 1 ? gy : gz);
-      const double sgn = lk >= 0.0 ? 1.0 : -1.0;
-      const V3 axis = sgn * col(r2, k);
-      V3 face = loc;
-      if (k == 0) face.x = sgn * s2.x; else if (k == 1) face.y = sgn * s2.y; else face.z = sgn * s2.z;
-      ct.dist = -gk - s1.x;
-      ct.p2 = c2 + mul(r2, face);
-      ct.p1 = c2 + mul(r2, loc) - s1.x * axis;
-    } else {
-      V3 d = w - u;
-      double nrm = sqrt(dot(d, d));
-      V3 n = nrm < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nrm) * d;
-      if (nrm < MK_MINVAL) nrm = 0.0;
-      ct.dist = nrm - s1.x;
-      ct.p1 = u + s1.x * n;
-      ct.p2 = w;
-    }
+    capsule_box_finish(a, b, u, w, s1, c2, r2, s2, ct);
   } else {  // box - box
     // bounding spheres first: most pairs are far apart
     const V3 d = c2 - c1;

@@ -98,7 +98,7 @@ struct MkFusedDesc {
 // (mink/limits/collision_avoidance_limit.py:192-199).  A problem with a pair in range goes to
 // the lane-per-problem kernel that builds the pairs' rows and solves the QP with them, and from
 // there to the general kernel only when that one cannot finish it (more rows in range than it
-// keeps, a pair type it has no lane routine for, no convergence of its dual iteration).
+// keeps, no convergence of its dual iteration).
 constexpr int MK_LANE_ROWS = 4;    // general rows per problem in the lane-per-problem solve
 constexpr int MK_MAX_CBODY = 6;    // bodies carrying collision geoms
 constexpr int MK_MAX_CSEG = 4;     // 1-dof joints between the chain's last body and such a body

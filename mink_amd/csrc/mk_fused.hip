@@ -878,8 +878,7 @@ MK_DEV void add_point_row(const MkFusedDesc* __restrict__ D, const MkFusedExt* _
 // distance (mink/limits/collision_avoidance_limit.py:187-210): G[k] = -n'(Jp2 - Jp1),
 // h[k] = gain (dist - d_min) / dt + relax (relax at dist <= d_min).  R.g must be zero on entry.
 // J is the unweighted body-frame Jacobian of the task frame at (Qw, tw, Rw).  Returns false when
-// the lane form cannot hold the problem: more than MK_LANE_ROWS rows, or a pair type without a
-// lane routine.
+// the lane form cannot hold the problem: more than MK_LANE_ROWS rows in range.
 template <int NC>
 MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const double* row,
                            const double (&J)[6][NC], Q4 Qw, V3 tw, const M3& Rw, double dt, LaneRows& R) {
@@ -921,31 +920,8 @@ MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* 
     }
     if (lower >= P.d_detect) continue;
     Contact ct;
-    bool active;
-    if (G1.type == 0 && G2.type == 6) {
-      plane_box(a.t, R1, b.t, q2m(b.q), s2, ct);
-      active = ct.dist < P.d_detect;
-    } else if (G1.type == 6 && G2.type == 6) {
-      active = box_box_lane(a.t, R1, v3(G1.size[0], G1.size[1], G1.size[2]), b.t, q2m(b.q), s2, P.d_detect, ct);
-    } else if (G1.type == 0 && G2.type == 2) {
-      const V3 n = col(R1, 2);
-      ct.dist = dot(b.t - a.t, n) - s2.x;
-      ct.p2 = b.t - s2.x * n;
-      ct.p1 = ct.p2 - ct.dist * n;
-      active = ct.dist < P.d_detect;
-    } else if (G1.type == 2 && G2.type == 2) {
-      const V3 d = b.t - a.t;
-      double nrm = sqrt(dot(d, d));
-      const V3 ax = nrm < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nrm) * d;
-      if (nrm < MK_MINVAL) nrm = 0.0;
-      ct.dist = nrm - G1.size[0] - s2.x;
-      ct.p1 = a.t + G1.size[0] * ax;
-      ct.p2 = b.t - s2.x * ax;
-      active = ct.dist < P.d_detect;
-    } else {
-      ok = false;   // capsules: the general kernel
-      continue;
-    }
+    const bool active = geom_distance_lane(G1.type, a.t, R1, v3(G1.size[0], G1.size[1], G1.size[2]), G2.type, b.t,
+                                           q2m(b.q), s2, P.d_detect, ct);
     if (!active) continue;
     if (R.n >= MK_LANE_ROWS) { ok = false; continue; }
     const int m = R.n++;

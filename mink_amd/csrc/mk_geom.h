@@ -205,3 +205,162 @@ MK_DEV void plane_box(V3 c1, const M3& r1, V3 c2, const M3& r2, V3 s2, Contact& 
   ct.p2 = pbest;
   ct.p1 = pbest - best * n;
 }
+
+// ---- the other closed forms (geom types ordered t1 <= t2; MuJoCo sizes: sphere radius = size.x,
+// capsule radius = size.x and half length along its z axis = size.y, box half extents) ----
+MK_DEV void plane_sphere(V3 c1, const M3& r1, V3 c2, V3 s2, Contact& ct) {
+  const V3 n = col(r1, 2);
+  ct.dist = dot(c2 - c1, n) - s2.x;
+  ct.p2 = c2 - s2.x * n;
+  ct.p1 = ct.p2 - ct.dist * n;
+}
+
+// Two spheres of radii ra, rb about u and w (the last step of every core + radius pair).
+MK_DEV void sphere_pair(V3 u, double ra, V3 w, double rb, Contact& ct) {
+  const V3 d = w - u;
+  double nrm = sqrt(dot(d, d));
+  const V3 ax = nrm < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nrm) * d;
+  if (nrm < MK_MINVAL) nrm = 0.0;
+  ct.dist = nrm - ra - rb;
+  ct.p1 = u + ra * ax;
+  ct.p2 = w - rb * ax;
+}
+
+MK_DEV void plane_capsule(V3 c1, const M3& r1, V3 c2, const M3& r2, V3 s2, Contact& ct) {
+  // the lower of the two end spheres
+  const V3 n = col(r1, 2), ax = col(r2, 2);
+  const V3 ea = c2 + s2.y * ax, eb = c2 - s2.y * ax;
+  const double da = dot(ea - c1, n) - s2.x, db = dot(eb - c1, n) - s2.x;
+  const V3 e = da <= db ? ea : eb;
+  ct.dist = da <= db ? da : db;
+  ct.p2 = e - s2.x * n;
+  ct.p1 = ct.p2 - ct.dist * n;
+}
+
+// Sphere (capsule = false) or capsule against a capsule: closest points of the axis segments
+// (a sphere is a segment of length 0), then two spheres.
+MK_DEV void round_capsule(bool capsule, V3 c1, const M3& r1, V3 s1, V3 c2, const M3& r2, V3 s2, Contact& ct) {
+  const V3 a2 = col(r2, 2);
+  V3 u = c1, w;
+  if (!capsule) {
+    const double t = fmin(fmax(dot(c1 - c2, a2), -s2.y), s2.y);
+    w = c2 + t * a2;
+  } else {
+    const V3 a1 = col(r1, 2);
+    seg_seg(c1 - s1.y * a1, c1 + s1.y * a1, c2 - s2.y * a2, c2 + s2.y * a2, u, w);
+  }
+  sphere_pair(u, s1.x, w, s2.x, ct);
+}
+
+// A point at `loc` (box frame) inside a box leaves through the nearest of the three faces on the
+// side of `side` (box frame; the point itself for a sphere, the capsule's centre for the middle
+// of the part of its axis inside the box -- that middle sits exactly on a mid-plane whenever the
+// axis pierces two opposite faces, so its own side is not defined): contact of a ball of radius
+// rad about the point; `centre` is the point in the world frame.
+MK_DEV void inside_box(V3 loc, V3 side, V3 centre, double rad, V3 c2, const M3& r2, V3 s2, Contact& ct) {
+  const V3 sg = v3(side.x >= 0.0 ? 1.0 : -1.0, side.y >= 0.0 ? 1.0 : -1.0, side.z >= 0.0 ? 1.0 : -1.0);
+  const double gx = s2.x - sg.x * loc.x, gy = s2.y - sg.y * loc.y, gz = s2.z - sg.z * loc.z;
+  const int k = (gx <= gy && gx <= gz) ? 0 : (gy <= gz ? 1 : 2);
+  const double gk = k == 0 ? gx : (k == 1 ? gy : gz);
+  const double sgn = comp(sg, k);
+  const V3 ax = sgn * col(r2, k);
+  V3 face = loc;
+  if (k == 0) face.x = sgn * s2.x; else if (k == 1) face.y = sgn * s2.y; else face.z = sgn * s2.z;
+  ct.dist = -gk - rad;
+  ct.p2 = c2 + mul(r2, face);
+  ct.p1 = centre - rad * ax;
+}
+
+MK_DEV void sphere_box(V3 c1, V3 s1, V3 c2, const M3& r2, V3 s2, Contact& ct) {
+  const V3 loc = mulT(r2, c1 - c2);
+  if (fabs(loc.x) > s2.x || fabs(loc.y) > s2.y || fabs(loc.z) > s2.z) {   // centre outside the box
+    const V3 cl = v3(fmin(fmax(loc.x, -s2.x), s2.x), fmin(fmax(loc.y, -s2.y), s2.y), fmin(fmax(loc.z, -s2.z), s2.z));
+    const V3 pb = c2 + mul(r2, cl);
+    const V3 d = c1 - pb;
+    double nrm = sqrt(dot(d, d));
+    const V3 ax = nrm < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nrm) * d;
+    if (nrm < MK_MINVAL) nrm = 0.0;
+    ct.dist = nrm - s1.x;
+    ct.p1 = c1 - s1.x * ax;
+    ct.p2 = pb;
+  } else {
+    inside_box(loc, loc, c1, s1.x, c2, r2, s2, ct);
+  }
+}
+
+// Capsule against a box.  Candidate k of the closest points of the axis segment [a, b] and the
+// box: 0, 1 the end points against the box, 2-13 the segment against the 12 box edges.
+constexpr int MK_CAPSULE_BOX_CANDIDATES = 14;
+MK_DEV void capsule_box_candidate(int k, V3 a, V3 b, V3 c2, const M3& r2, V3 s2, V3& u, V3& w) {
+  if (k < 2) {
+    u = k == 0 ? a : b;
+    w = box_closest(u, c2, r2, s2);
+  } else {
+    V3 b0, b1;
+    box_edge(c2, r2, s2, k - 2, b0, b1);
+    seg_seg(a, b, b0, b1, u, w);
+  }
+}
+// With the closest points (u on the axis segment, w on the box) found: a segment that passes
+// through the box leaves it, from the middle of the part inside, through the nearest face on the
+// capsule centre's side; otherwise a sphere about u against the point w.
+MK_DEV void capsule_box_finish(V3 a, V3 b, V3 u, V3 w, V3 s1, V3 c2, const M3& r2, V3 s2, Contact& ct) {
+  const V3 la = mulT(r2, a - c2), ld = mulT(r2, b - a);
+  double t0 = 0.0, t1c = 1.0;
+  for (int k = 0; k < 3; ++k) {
+    const double lk = comp(la, k), dk = comp(ld, k), hk = comp(s2, k);
+    if (fabs(dk) < 1e-300) {
+      if (fabs(lk) > hk) { t0 = 1.0; t1c = 0.0; }
+    } else {
+      const double ta = (-hk - lk) / dk, tb = (hk - lk) / dk;
+      t0 = fmax(t0, fmin(ta, tb));
+      t1c = fmin(t1c, fmax(ta, tb));
+    }
+  }
+  if (t0 <= t1c) {
+    const V3 loc = la + (0.5 * (t0 + t1c)) * ld;
+    inside_box(loc, la + 0.5 * ld, c2 + mul(r2, loc), s1.x, c2, r2, s2, ct);
+  } else {
+    const V3 d = w - u;
+    double nrm = sqrt(dot(d, d));
+    const V3 n = nrm < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nrm) * d;
+    if (nrm < MK_MINVAL) nrm = 0.0;
+    ct.dist = nrm - s1.x;
+    ct.p1 = u + s1.x * n;
+    ct.p2 = w;
+  }
+}
+
+// mj_geomDistance of a primitive pair (plane 0, sphere 2, capsule 3, box 6; t1 <= t2, not two
+// planes) by one lane.  Returns false for "at least distmax apart".
+MK_DEV bool geom_distance_lane(int t1, V3 c1, const M3& r1, V3 s1, int t2, V3 c2, const M3& r2, V3 s2, double distmax,
+                               Contact& ct) {
+  if (t1 == 0 && t2 == 6) {
+    plane_box(c1, r1, c2, r2, s2, ct);
+  } else if (t1 == 0 && t2 == 2) {
+    plane_sphere(c1, r1, c2, s2, ct);
+  } else if (t1 == 0 && t2 == 3) {
+    plane_capsule(c1, r1, c2, r2, s2, ct);
+  } else if (t1 == 2 && t2 == 2) {
+    sphere_pair(c1, s1.x, c2, s2.x, ct);
+  } else if ((t1 == 2 || t1 == 3) && t2 == 3) {
+    round_capsule(t1 == 3, c1, r1, s1, c2, r2, s2, ct);
+  } else if (t1 == 2 && t2 == 6) {
+    sphere_box(c1, s1, c2, r2, s2, ct);
+  } else if (t1 == 3 && t2 == 6) {
+    const V3 ax = col(r1, 2);
+    const V3 a = c1 - s1.y * ax, b = c1 + s1.y * ax;
+    double best = INFINITY;
+    V3 u = a, w = c2;
+    for (int k = 0; k < MK_CAPSULE_BOX_CANDIDATES; ++k) {
+      V3 uk, wk;
+      capsule_box_candidate(k, a, b, c2, r2, s2, uk, wk);
+      const double dd = dot(uk - wk, uk - wk);
+      if (dd < best) { best = dd; u = uk; w = wk; }
+    }
+    capsule_box_finish(a, b, u, w, s1, c2, r2, s2, ct);
+  } else {
+    return box_box_lane(c1, r1, s1, c2, r2, s2, distmax, ct);
+  }
+  return ct.dist < distmax;
+}

@@ -446,8 +446,9 @@ def _capsule_box(c1, r1, s1, c2, r2, h2):
     Axis segment outside the box: exact closest points of the segment and the box -- the two
     end points against the box, then the segment against the 12 box edges, in this fixed
     order, first strict minimum wins -- and dist = that distance - radius.  Axis segment
-    through the box: the point in the middle of the part inside the box leaves through its
-    nearest face (the rule of sphere-box for a centre inside), dist = -(gap + radius)."""
+    through the box: the point in the middle of the part inside the box leaves through the
+    nearest of the three faces on the capsule centre's side (for a sphere centre inside a box
+    this is the nearest face), dist = -(gap + radius)."""
     ax = r1[:, 2]
     a, b = c1 - ax * s1[1], c1 + ax * s1[1]
     best, u, w = np.inf, None, None
@@ -473,10 +474,13 @@ def _capsule_box(c1, r1, s1, c2, r2, h2):
             ta, tb = (-h2[k] - la[k]) / ld[k], (h2[k] - la[k]) / ld[k]
             t0, t1 = max(t0, min(ta, tb)), min(t1, max(ta, tb))
     if t0 <= t1:
+        # (the side of each axis is the one the capsule's centre lies on: the middle of the part
+        # inside sits exactly on a mid-plane whenever the segment pierces two opposite faces)
         loc = la + 0.5 * (t0 + t1) * ld
-        gap = h2 - np.abs(loc)
+        side = np.where(la + 0.5 * ld >= 0.0, 1.0, -1.0)
+        gap = h2 - side * loc
         k = int(np.argmin(gap))
-        sgn = 1.0 if loc[k] >= 0 else -1.0
+        sgn = side[k]
         axis = r2[:, k] * sgn
         face = loc.copy()
         face[k] = sgn * h2[k]

@@ -1,9 +1,9 @@
 """Staged solve on a synthetic gripper arm with every primitive pair type: the lane-per-problem
-rows stage (box - box, box - plane, sphere - sphere, sphere - plane; chain-attached, free and
-world bodies; finger joints behind the chain) against the general kernel and the numpy
+rows stage (every pair of planes, spheres, capsules and boxes; chain-attached, free and world
+bodies; finger joints behind the chain) against the general kernel and the numpy
 restatement of mink.solve_ik with a CollisionAvoidanceLimit
-(mink/limits/collision_avoidance_limit.py:187-229), and what it hands on (capsule and
-sphere - box pairs) through the general kernel."""
+(mink/limits/collision_avoidance_limit.py:187-229), and what it hands on (more rows in range than
+it keeps) through the general kernel."""
 import os
 
 import numpy as np
@@ -93,7 +93,7 @@ def solve_general(dm, tasks, limits, q, tg):
 
 @pytest.mark.parametrize("groups,expect_left", [
     ([(["pad_a", "pad_b"], ["brick_geom", "floor", "pillar"]), (["tip_b"], ["ball_geom", "floor"])], "few"),   # lane routines only
-    ([(list(HAND), list(OBJECTS) + ["floor", "pillar"])], "some"),                             # + capsule, sphere - box
+    ([(list(HAND), list(OBJECTS) + ["floor", "pillar"])], "crowded"),                          # + capsule, sphere - box pairs
 ])
 def test_lane_rows_stage_on_gripper_arm(env, groups, expect_left):
     model, dm = env
@@ -132,13 +132,14 @@ def test_lane_rows_stage_on_gripper_arm(env, groups, expect_left):
     v_f, _ = free.solve(q, tg, DT, DAMPING)
     binding = ((v_f - v_g).abs().amax(dim=1) > 1e-6) & ~left
     print("finished by the lane stage with a binding row:", int(binding.sum()))
-    assert int(binding.sum()) > (100 if expect_left == "few" else 10)
+    assert int(binding.sum()) > 100
     if expect_left == "few":
         # left: more rows than the lane form keeps, or a dual iteration that stalls on a piece where
         # every dof of a violated row sits at a bound (zero curvature); rare, and the general kernel's
         assert int(left.sum()) <= B // 100
     else:
-        assert int(left.sum()) > 50
+        # 15 pairs around three fingers: many problems have more than MK_LANE_ROWS = 4 rows in range
+        assert bool((in_range[left] > 4).double().mean() > 0.9)
 
 
 def test_lane_rows_rows_against_numpy_restatement(env):
