@@ -204,6 +204,26 @@ extern "C" void hostsim_box_box(const double* c1, const double* q1, const double
   }
 }
 
+// geom_distance_lane on B pairs of primitives of types (t1 <= t2): centre [B,3], quaternion [B,4]
+// (wxyz), MuJoCo size [B,3] per geom; out [B,8] = (in range, dist, p1, p2).
+extern "C" void hostsim_geom_distance(int t1, const double* c1, const double* q1, const double* s1, int t2,
+                                      const double* c2, const double* q2, const double* s2, int B, double distmax,
+                                      double* out) {
+  for (int b = 0; b < B; ++b) {
+    const double *a = q1 + 4 * b, *e = q2 + 4 * b;
+    Contact ct;
+    ct.dist = 0.0;
+    ct.p1 = ct.p2 = v3(0, 0, 0);
+    const bool in = geom_distance_lane(t1, v3(c1[3 * b], c1[3 * b + 1], c1[3 * b + 2]), q2m(Q4{a[0], a[1], a[2], a[3]}),
+                                       v3(s1[3 * b], s1[3 * b + 1], s1[3 * b + 2]), t2,
+                                       v3(c2[3 * b], c2[3 * b + 1], c2[3 * b + 2]), q2m(Q4{e[0], e[1], e[2], e[3]}),
+                                       v3(s2[3 * b], s2[3 * b + 1], s2[3 * b + 2]), distmax, ct);
+    double* o = out + 8 * b;
+    o[0] = in ? 1.0 : 0.0; o[1] = ct.dist;
+    o[2] = ct.p1.x; o[3] = ct.p1.y; o[4] = ct.p1.z; o[5] = ct.p2.x; o[6] = ct.p2.y; o[7] = ct.p2.z;
+  }
+}
+
 // The device waypoint generator on B (current pose, goal pose) pairs (wxyz_xyz each):
 // commanded poses [B, 7] and reached flags [B].
 extern "C" void hostsim_waypoint_step(const double* cur, const double* goal, int B, double pos_thr, double pos_step,

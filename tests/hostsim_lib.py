@@ -112,3 +112,15 @@ def box_box(c1, q1, h1, c2, q2, h2, distmax):
     out = np.zeros((B, 8))
     h.hostsim_box_box(*[_ptr(a) for a in arrs], C.c_int(B), C.c_double(distmax), _ptr(out))
     return out[:, 0] > 0, out[:, 1], out[:, 2:5], out[:, 5:8]
+
+
+def geom_distance(t1, c1, q1, s1, t2, c2, q2, s2, distmax):
+    """The device's one-lane distance of primitive pairs of types (t1 <= t2) on B pairs:
+    (in range [B], dist [B], p1 [B,3], p2 [B,3])."""
+    h = _load()
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (c1, q1, s1, c2, q2, s2)]
+    B = arrs[0].shape[0]
+    out = np.zeros((B, 8))
+    h.hostsim_geom_distance(C.c_int(t1), _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), C.c_int(t2), _ptr(arrs[3]),
+                            _ptr(arrs[4]), _ptr(arrs[5]), C.c_int(B), C.c_double(distmax), _ptr(out))
+    return out[:, 0] > 0, out[:, 1], out[:, 2:5], out[:, 5:8]

@@ -104,3 +104,46 @@ def test_box_box_search_against_exhaustive_enumeration():
             v2 = np.abs(np.abs(r2.T @ (w - c2[i])) - h2[i]) < 1e-12
             n_edge += int(v1.sum() == 2 and v2.sum() == 2)
     assert n_edge > 200 and n_pen > 200, (n_edge, n_pen)
+
+
+@pytest.mark.parametrize("t1,t2", [(0, 2), (0, 3), (0, 6), (2, 2), (2, 3), (2, 6), (3, 3), (3, 6), (6, 6)])
+def test_lane_distance_of_every_primitive_pair(t1, t2):
+    """geom_distance_lane (the closed forms both kernels share) against the numpy restatement of
+    mj_geomDistance for planes (0), spheres (2), capsules (3) and boxes (6), separated and
+    penetrating -- including capsule axes that pierce a thin box through two opposite faces, where
+    the exit side is the capsule centre's."""
+    from types import SimpleNamespace
+    from oracle import mjlite
+
+    rng = np.random.default_rng(100 * t1 + t2)
+    n = 600
+    def quat(n):
+        q = rng.normal(size=(n, 4))
+        return q / np.linalg.norm(q, axis=1, keepdims=True)
+    def size(t):
+        s = rng.uniform(0.01, 0.08, (n, 3))
+        if t == 6:
+            s[: n // 3, 0] = rng.uniform(0.003, 0.008, n // 3)     # thin plates
+        return s
+    q1, q2, s1, s2 = quat(n), quat(n), size(t1), size(t2)
+    c1 = rng.uniform(-0.05, 0.05, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    c2 = c1 + d * rng.uniform(0.0, 0.2, (n, 1))
+    inr, dist, p1, p2 = hs.geom_distance(t1, c1, q1, s1, t2, c2, q2, s2, 0.05)
+    n_in = n_pen = 0
+    for i in range(n):
+        m = SimpleNamespace(geom_type=np.array([t1, t2]), geom_size=np.stack([s1[i], s2[i]]), geom_dataid=np.array([-1, -1]))
+        dd = SimpleNamespace(geom_xpos=np.stack([c1[i], c2[i]]),
+                             geom_xmat=np.stack([mjlite.mju_quat2Mat(q1[i]), mjlite.mju_quat2Mat(q2[i])]))
+        dr, fromto = mjlite.mj_geomDistance(m, dd, 0, 1, 0.05)
+        if dr == 0.05:
+            assert not inr[i], (i, dist[i])
+            continue
+        assert inr[i]
+        n_in += 1
+        n_pen += dr < 0
+        assert abs(dist[i] - dr) <= 1e-12, (i, dist[i], dr)
+        np.testing.assert_allclose(p1[i], fromto[:3], rtol=0, atol=1e-9, err_msg=f"pair {i}")
+        np.testing.assert_allclose(p2[i], fromto[3:], rtol=0, atol=1e-9, err_msg=f"pair {i}")
+    assert n_in > 100 and n_pen > 30, (n_in, n_pen)
