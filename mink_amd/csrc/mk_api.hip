@@ -569,7 +569,21 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
     memcpy(G.lq, &m.geom_quat[4 * g], 32);
     memcpy(G.size, &m.geom_size[3 * g], 24);
     const double* sz = G.size;
-    G.rbound = G.type == 2 ? sz[0] : G.type == 3 ? sz[0] + sz[1] : G.type == 6 ? std::sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]) : 0.0;
+    G.bc[0] = G.bc[1] = G.bc[2] = 0.0;
+    switch (G.type) {
+      case 2: G.rbound = sz[0]; break;
+      case 3: G.rbound = sz[0] + sz[1]; break;
+      case 4: G.rbound = std::max(sz[0], std::max(sz[1], sz[2])); break;
+      case 5: G.rbound = std::sqrt(sz[0] * sz[0] + sz[1] * sz[1]); break;
+      case 6: G.rbound = std::sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]); break;
+      case 7: {
+        const int k = m.geom_dataid[g];
+        memcpy(G.bc, &m.mesh_center[3 * k], 24);
+        G.rbound = m.mesh_radius[k];
+        break;
+      }
+      default: G.rbound = 0.0;
+    }
     return geom_slot[g] = X->ncgeom++;
   };
   for (int l = 0; l < nlimit; ++l) {
@@ -579,10 +593,9 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
       int g1 = L.index[2 * k], g2 = L.index[2 * k + 1];
       if (g1 < 0 || g1 >= m.ngeom || g2 < 0 || g2 >= m.ngeom) { why = "geom id out of range"; return false; }
       if (m.geom_type[g1] > m.geom_type[g2]) std::swap(g1, g2);
-      const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
-      const bool ok = (t1 == 0 && (t2 == 2 || t2 == 3 || t2 == 6)) || (t1 == 2 && (t2 == 2 || t2 == 3 || t2 == 6)) ||
-                      (t1 == 3 && (t2 == 3 || t2 == 6)) || (t1 == 6 && t2 == 6);
-      if (!ok) { why = "geom pair types without a distance routine"; return false; }
+      // pairs without a closed form (ellipsoid, cylinder, mesh) are screened by their bounding
+      // spheres here and, when in range, solved by the general kernel
+      if (!pair_supported(m, g1, g2, nullptr, why)) return false;
       if (X->ncpair >= MK_MAX_CPAIR) { why = "too many collision pairs"; return false; }
       const int s1 = coll_geom(g1), s2 = coll_geom(g2);
       if (s1 < 0 || s2 < 0) return false;

@@ -98,7 +98,8 @@ struct MkFusedDesc {
 // (mink/limits/collision_avoidance_limit.py:192-199).  A problem with a pair in range goes to
 // the lane-per-problem kernel that builds the pairs' rows and solves the QP with them, and from
 // there to the general kernel only when that one cannot finish it (more rows in range than it
-// keeps, no convergence of its dual iteration).
+// keeps, a pair without a closed form -- ellipsoid, cylinder, mesh --, no convergence of its dual
+// iteration).
 constexpr int MK_LANE_ROWS = 4;    // general rows per problem in the lane-per-problem solve
 constexpr int MK_MAX_CBODY = 6;    // bodies carrying collision geoms
 constexpr int MK_MAX_CSEG = 4;     // 1-dof joints between the chain's last body and such a body
@@ -121,7 +122,8 @@ struct MkCollBody {
 struct MkCollGeom {
   int32_t body, type;     // index into cbody, MuJoCo geom type
   double lq[4], lp[3];    // pose in the body frame
-  double size[3], rbound; // rbound: radius of a bounding sphere about the geom centre
+  double size[3], rbound; // rbound: radius of a bounding sphere about bc
+  double bc[3], pad;      // centre of the bounding sphere in the geom frame (meshes; 0 otherwise)
 };
 struct MkCollPair {
   int32_t g1, g2;         // indices into cgeom, ordered by geom type

@@ -756,6 +756,9 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
     const MkCollGeom& G1 = X->cgeom[g1];
     const MkCollGeom& G2 = X->cgeom[g2];
     double lower;
+    // centres of the bounding spheres (off the geom centre for meshes only)
+    const V3 ac = a.t + qrot(a.q, v3(G1.bc[0], G1.bc[1], G1.bc[2]));
+    const V3 bcw = b.t + qrot(b.q, v3(G2.bc[0], G2.bc[1], G2.bc[2]));
     if (G1.type == 0) {   // plane: height of the other geom's centre minus its extent along the normal
       const M3 R1 = q2m(a.q);
       const V3 n = v3(R1.m[2], R1.m[5], R1.m[8]);
@@ -765,9 +768,9 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
         const V3 nl = mulT(R2, n);
         ext = fabs(nl.x) * G2.size[0] + fabs(nl.y) * G2.size[1] + fabs(nl.z) * G2.size[2];
       }
-      lower = dot(b.t - a.t, n) - ext;
+      lower = dot(bcw - a.t, n) - ext;
     } else {
-      const V3 d = b.t - a.t;
+      const V3 d = bcw - ac;
       lower = sqrt(dot(d, d)) - G1.rbound - G2.rbound;
       if (G1.type == 6 && G2.type == 6 && lower < d_detect) {
         // two boxes: the largest gap along the 15 candidate separating axes
@@ -878,7 +881,8 @@ MK_DEV void add_point_row(const MkFusedDesc* __restrict__ D, const MkFusedExt* _
 // distance (mink/limits/collision_avoidance_limit.py:187-210): G[k] = -n'(Jp2 - Jp1),
 // h[k] = gain (dist - d_min) / dt + relax (relax at dist <= d_min).  R.g must be zero on entry.
 // J is the unweighted body-frame Jacobian of the task frame at (Qw, tw, Rw).  Returns false when
-// the lane form cannot hold the problem: more than MK_LANE_ROWS rows in range.
+// the lane form cannot hold the problem: more than MK_LANE_ROWS rows in range, or a pair without a
+// closed form (ellipsoid, cylinder, mesh) that may be in range.
 template <int NC>
 MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const double* row,
                            const double (&J)[6][NC], Q4 Qw, V3 tw, const M3& Rw, double dt, LaneRows& R) {
@@ -911,14 +915,18 @@ MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* 
     const M3 R1 = q2m(a.q);
     const V3 s2 = v3(G2.size[0], G2.size[1], G2.size[2]);
     // bounding spheres first (the bound behind which the general kernel skips the pair, too)
+    const V3 bcw = b.t + qrot(b.q, v3(G2.bc[0], G2.bc[1], G2.bc[2]));
     double lower;
     if (G1.type == 0) {
-      lower = dot(b.t - a.t, col(R1, 2)) - G2.rbound;
+      lower = dot(bcw - a.t, col(R1, 2)) - G2.rbound;
     } else {
-      const V3 d = b.t - a.t;
+      const V3 d = bcw - (a.t + qrot(a.q, v3(G1.bc[0], G1.bc[1], G1.bc[2])));
       lower = sqrt(dot(d, d)) - G1.rbound - G2.rbound;
     }
     if (lower >= P.d_detect) continue;
+    const bool closed1 = G1.type == 0 || G1.type == 2 || G1.type == 3 || G1.type == 6;
+    const bool closed2 = G2.type == 2 || G2.type == 3 || G2.type == 6;
+    if (!closed1 || !closed2) { ok = false; continue; }   // support-mapping pair: the general kernel
     Contact ct;
     const bool active = geom_distance_lane(G1.type, a.t, R1, v3(G1.size[0], G1.size[1], G1.size[2]), G2.type, b.t,
                                            q2m(b.q), s2, P.d_detect, ct);

@@ -59,7 +59,7 @@ def inputs(model, dm, n, seed):
     dev = dm.device
     tq = torch.tensor(q, device=dev)
     # loose objects near a geom of the hand in most problems, elsewhere in the rest
-    for name, body in (("brick_geom", "brick"), ("ball_geom", "ball"), ("rod_geom", "rod")):
+    for name, body in (("brick_geom", "brick"), ("ball_geom", "ball"), ("rod_geom", "rod"), ("can_geom", "can")):
         adr = int(model.jnt_qposadr[model.body_jntadr[model.body_id(body)]])
         pick = rng.integers(0, len(HAND), n)
         pos = np.zeros((n, 3))
@@ -207,3 +207,35 @@ def test_staged_loop_matches_general_loop(near):
     assert float((ra["v"] - rb["v"])[same].abs().max()) <= 1e-7
     if near:
         assert float((ra["iters"] < 12).double().mean()) > 0.3
+
+
+def test_staged_solve_with_pairs_without_closed_form(env):
+    """Cylinder and ellipsoid pairs in a staged problem: screened by their bounding spheres in the
+    structured kernel, solved by the general kernel (support mappings) when in range."""
+    model, dm = env
+    groups = [(["pad_a", "pad_b"], ["brick_geom", "can_geom", "egg", "floor"]), (["tip_b"], ["can_geom", "egg"])]
+    tasks, limits = specs(model, groups)
+    B = 4096
+    q, tg = inputs(model, dm, B, 8)
+    staged = DeviceProblem(dm, tasks, limits)
+    assert staged.staged
+    v_s, st_s = staged.solve(q, tg, DT, DAMPING)
+    (v_g, st_g), general = solve_general(dm, tasks, limits, q, tg)
+    assert int(st_g.abs().sum()) == 0 and torch.equal(st_s, st_g)
+    d = (v_s - v_g).abs().amax(dim=1)
+    print("staged vs general with cylinder / ellipsoid pairs: max |dv| =", float(d.max()))
+    assert float(d.max()) <= 1e-9
+    P, c, G, h = general.build_qp(q, tg, DT, DAMPING)
+    npair = len(limits[2]["index"]) // 2
+    names = [(model.geom_names[a], model.geom_names[b]) for a, b in np.array(limits[2]["index"]).reshape(-1, 2)]
+    fin = torch.isfinite(h[:, -npair:])
+    convex_cols = [k for k, (a, b) in enumerate(names) if "can_geom" in (a, b) or "egg" in (a, b)]
+    assert int(fin[:, convex_cols].sum()) > 200          # rows of such pairs are in range for many problems
+    os.environ["MK_NO_GENERAL_STAGE"] = "1"
+    try:
+        _, st_l = staged.solve(q, tg, DT, DAMPING)
+    finally:
+        del os.environ["MK_NO_GENERAL_STAGE"]
+    left = st_l != 0
+    assert bool(left[fin[:, convex_cols].any(dim=1)].all())      # every one of them went to the general kernel
+    assert int((~left).sum()) > B // 4                           # and the rest did not
