@@ -506,26 +506,31 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
   }
 
   // ---- extension: collision screen ----
-  int tip = path.back();   // deepest body of the path: its anchor leads from the last chain slot
   std::vector<int> body_slot(m.nbody, -1);
   auto coll_body = [&](int gb) -> int {
     if (body_slot[gb] >= 0) return body_slot[gb];
     if (X->ncbody >= MK_MAX_CBODY) { why = "too many bodies with collision geoms"; return -1; }
     MkCollBody CB;
     memset(&CB, 0, sizeof(CB));
-    // bodies from gb upwards until the tip of the chain, a free-joint body or the world
+    // bodies from gb upwards until a body of the chain, a free-joint body or the world
     std::vector<int> up;
     int b = gb;
-    while (b != 0 && b != tip && !(m.body_jntnum[b] == 1 && m.jnt_type[m.body_jntadr[b]] == MK_JNT_FREE)) {
+    while (b != 0 && anchor[b].slot == -2 && !(m.body_jntnum[b] == 1 && m.jnt_type[m.body_jntadr[b]] == MK_JNT_FREE)) {
       up.insert(up.begin(), b);
       b = m.body_parentid[b];
     }
     double pp[3] = {0, 0, 0}, pq[4] = {1, 0, 0, 0};
-    if (b == tip && b != 0) {
+    if (b != 0 && anchor[b].slot >= 0) {
+      // carried by the frame behind chain joint `slot` (the last one: the body the task frame is on)
       CB.kind = MK_CB_TIP;
-      memcpy(pp, anchor[tip].pos, sizeof(pp));
-      memcpy(pq, anchor[tip].quat, sizeof(pq));
-      if (anchor[tip].slot != nc - 1) { why = "internal: tip anchor"; return -1; }
+      CB.slot = anchor[b].slot;
+      memcpy(pp, anchor[b].pos, sizeof(pp));
+      memcpy(pq, anchor[b].quat, sizeof(pq));
+    } else if (b != 0 && anchor[b].slot == -1) {
+      // on the path in front of the first joint: fixed in the world
+      CB.kind = MK_CB_WORLD;
+      memcpy(pp, anchor[b].pos, sizeof(pp));
+      memcpy(pq, anchor[b].quat, sizeof(pq));
     } else if (b == 0) {
       CB.kind = MK_CB_WORLD;
     } else {
@@ -534,7 +539,6 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
       CB.free_dofadr = m.jnt_dofadr[m.body_jntadr[b]];
     }
     for (int c : up) {
-      if (anchor[c].slot != -2) { why = "collision geom on an inner body of the task chain"; return -1; }
       if (m.body_mocapid[c] >= 0) { why = "collision geom on a mocap body"; return -1; }
       compose(pp, pq, &m.body_pos[3 * c], &m.body_quat[4 * c]);
       for (int j = m.body_jntadr[c]; j < m.body_jntadr[c] + m.body_jntnum[c]; ++j) {

@@ -102,10 +102,10 @@ struct MkFusedDesc {
 // iteration).
 constexpr int MK_LANE_ROWS = 4;    // general rows per problem in the lane-per-problem solve
 constexpr int MK_MAX_CBODY = 6;    // bodies carrying collision geoms
-constexpr int MK_MAX_CSEG = 4;     // 1-dof joints between the chain's last body and such a body
+constexpr int MK_MAX_CSEG = 4;     // 1-dof joints between the chain and such a body
 constexpr int MK_MAX_CGEOM = 12;
 constexpr int MK_MAX_CPAIR = 16;
-enum { MK_CB_WORLD = 0, MK_CB_TIP = 1, MK_CB_FREE = 2 };
+enum { MK_CB_WORLD = 0, MK_CB_TIP = 1, MK_CB_FREE = 2 };   // TIP: carried by a joint frame of the chain
 constexpr int32_t MK_STATUS_PENDING = 1 << 30;   // in a status entry: the general kernel still has to solve it
 
 struct MkCollSeg {        // like MkSegC: fixed transform, then motion about / along z
@@ -115,6 +115,7 @@ struct MkCollSeg {        // like MkSegC: fixed transform, then motion about / a
 };
 struct MkCollBody {
   int32_t kind, nseg, free_qadr, free_dofadr;
+  int32_t slot, pad0;     // MK_CB_TIP: the chain slot whose joint frame carries the body (nc - 1: the last one)
   MkCollSeg seg[MK_MAX_CSEG];
   double tq[4], tp[3];    // fixed transform behind the last joint (WORLD: the world pose)
   double pad2;

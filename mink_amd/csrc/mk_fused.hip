@@ -700,6 +700,21 @@ struct PoseQT {
 };
 MK_DEV PoseQT pose_then(PoseQT a, Q4 bq, V3 bt) { return PoseQT{qmul(a.q, bq), a.t + qrot(a.q, bt)}; }
 
+// World pose of the frame behind chain joint `slot` (forward composition of the canonical
+// segments 0..slot at the lane's q): where a collision body on an inner link of the chain hangs.
+MK_DEV PoseQT chain_frame_pose(const MkFusedDesc* __restrict__ D, const double* row, int slot) {
+  PoseQT p = PoseQT{Q4{1, 0, 0, 0}, v3(0, 0, 0)};
+  for (int i = 0; i <= slot; ++i) {
+    const MkSegC& S = D->segc[i];
+    p = pose_then(p, Q4{S.pq[0], S.pq[1], S.pq[2], S.pq[3]}, v3(S.pp[0], S.pp[1], S.pp[2]));
+    const double qv = D->seg_dof[i] >= 0 ? row[D->seg_qadr[i]] : 0.0;
+    double sn, cs;
+    mk_sincos(0.5 * (S.hinge * qv), &sn, &cs);
+    p = pose_then(p, Q4{cs, 0.0, 0.0, sn}, v3(0.0, 0.0, S.slide * qv));
+  }
+  return p;
+}
+
 // True when some CollisionAvoidanceLimit pair of the problem may be within its detection
 // distance: conservative lower bounds of the pair distances (bounding spheres; the support
 // extent of a box against a plane; the separating-axis gaps of two boxes) -- the same bounds
@@ -719,7 +734,7 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
     const MkCollBody& CB = X->cbody[b];
     PoseQT p = PoseQT{Q4{1, 0, 0, 0}, v3(0, 0, 0)};
     if (CB.kind == MK_CB_TIP) {
-      p = tip;
+      p = CB.slot >= D->nc - 1 ? tip : chain_frame_pose(D, row, CB.slot);
       for (int sidx = 0; sidx < CB.nseg; ++sidx) {
         const MkCollSeg& S = CB.seg[sidx];
         p = pose_then(p, Q4{S.pq[0], S.pq[1], S.pq[2], S.pq[3]}, v3(S.pp[0], S.pp[1], S.pp[2]));
@@ -814,11 +829,12 @@ struct LaneRows {
 };
 
 // World pose of collision body b; `tip` is the frame behind the chain's last joint.
-MK_DEV PoseQT coll_body_pose(const MkFusedExt* __restrict__ X, const double* row, PoseQT tip, int b) {
+MK_DEV PoseQT coll_body_pose(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const double* row,
+                             PoseQT tip, int b) {
   const MkCollBody& CB = X->cbody[b];
   PoseQT p = PoseQT{Q4{1, 0, 0, 0}, v3(0, 0, 0)};
   if (CB.kind == MK_CB_TIP) {
-    p = tip;
+    p = CB.slot >= D->nc - 1 ? tip : chain_frame_pose(D, row, CB.slot);
     for (int sidx = 0; sidx < CB.nseg; ++sidx) {
       const MkCollSeg& S = CB.seg[sidx];
       p = pose_then(p, Q4{S.pq[0], S.pq[1], S.pq[2], S.pq[3]}, v3(S.pp[0], S.pp[1], S.pp[2]));
@@ -839,22 +855,24 @@ MK_DEV PoseQT coll_body_pose(const MkFusedExt* __restrict__ X, const double* row
 // collision body b (mj_jac as used by compute_contact_normal_jacobian,
 // mink/limits/collision_avoidance_limit.py:83-110).  On the chain dofs the body-frame Jacobian of
 // the task frame (J, still unweighted; task frame at (tw, Rw)) gives the motion of every point
-// of the chain's last body: n' Rw (v_j + w_j x r) = (Rw'n).v_j + (r x Rw'n).w_j with r = Rw'(point - tw).
+// behind a joint: n' Rw (v_j + w_j x r) = (Rw'n).v_j + (r x Rw'n).w_j with r = Rw'(point - tw).
 template <int NC>
 MK_DEV void add_point_row(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const double* row,
                           const double (&J)[6][NC], V3 tw, const M3& Rw, PoseQT tip, int b, V3 point, V3 n, double s,
                           const LaneRows& R, int m) {
   const MkCollBody& CB = X->cbody[b];
   if (CB.kind == MK_CB_TIP) {
+    // (a joint moves every point behind it the same way whichever link the point is on, so the
+    // task frame's columns serve any chain body: the columns of the joints behind its slot vanish)
     const V3 nt = mulT(Rw, n), r = mulT(Rw, point - tw);
     const V3 mt = cross(r, nt);
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const int dof = D->seg_dof[j];
       const double val = nt.x * J[0][j] + nt.y * J[1][j] + nt.z * J[2][j] + mt.x * J[3][j] + mt.y * J[4][j] + mt.z * J[5][j];
-      if (dof >= 0) R.at(m, dof) += s * val;
+      if (dof >= 0 && j <= CB.slot) R.at(m, dof) += s * val;
     }
-    PoseQT f = tip;
+    PoseQT f = CB.slot >= D->nc - 1 ? tip : chain_frame_pose(D, row, CB.slot);
     for (int sidx = 0; sidx < CB.nseg; ++sidx) {
       const MkCollSeg& S = CB.seg[sidx];
       f = pose_then(f, Q4{S.pq[0], S.pq[1], S.pq[2], S.pq[3]}, v3(S.pp[0], S.pp[1], S.pp[2]));
@@ -897,9 +915,9 @@ MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* 
   int cached = -1;
   PoseQT cpose = tip;
   auto body_pose = [&](int b) -> PoseQT {
-    if (X->cbody[b].kind != MK_CB_TIP) return coll_body_pose(X, row, tip, b);
+    if (X->cbody[b].kind != MK_CB_TIP) return coll_body_pose(D, X, row, tip, b);
     if (b != cached) {
-      cpose = coll_body_pose(X, row, tip, b);
+      cpose = coll_body_pose(D, X, row, tip, b);
       cached = b;
     }
     return cpose;

@@ -46,7 +46,7 @@ def specs(model, groups):
     return tasks, limits
 
 
-def inputs(model, dm, n, seed):
+def inputs(model, dm, n, seed, near=HAND):
     rng = np.random.default_rng(seed)
     q = np.tile(model.qpos0, (n, 1))
     for j in range(7):
@@ -58,12 +58,12 @@ def inputs(model, dm, n, seed):
         qs[:, j] = np.clip(q[:, j] + rng.uniform(-0.3, 0.3, n) * (hi - lo) * 0.2, lo, hi)
     dev = dm.device
     tq = torch.tensor(q, device=dev)
-    # loose objects near a geom of the hand in most problems, elsewhere in the rest
+    # loose objects near one of the geoms `near` in most problems, elsewhere in the rest
     for name, body in (("brick_geom", "brick"), ("ball_geom", "ball"), ("rod_geom", "rod"), ("can_geom", "can")):
         adr = int(model.jnt_qposadr[model.body_jntadr[model.body_id(body)]])
-        pick = rng.integers(0, len(HAND), n)
+        pick = rng.integers(0, len(near), n)
         pos = np.zeros((n, 3))
-        for k, g in enumerate(HAND):
+        for k, g in enumerate(near):
             sel = np.nonzero(pick == k)[0]
             pos[sel] = dm.frame_pose(tq[sel].contiguous(), L.FRAME_TYPES["geom"], model.geom_id(g))[:, 4:].cpu().numpy()
         d = rng.normal(size=(n, 3))
@@ -239,3 +239,50 @@ def test_staged_solve_with_pairs_without_closed_form(env):
     left = st_l != 0
     assert bool(left[fin[:, convex_cols].any(dim=1)].all())      # every one of them went to the general kernel
     assert int((~left).sum()) > B // 4                           # and the rest did not
+
+
+def test_staged_solve_with_geoms_on_inner_links(env):
+    """Collision geoms on links inside the task chain (capsules of the arm's links against a loose
+    box, the pillar, the floor and a finger pad): their rows only have the columns of the joints
+    up to their link (mj_jac, mink/limits/collision_avoidance_limit.py:83-110)."""
+    model, dm = env
+    groups = [(["l2_geom", "l3_geom"], ["brick_geom", "pillar", "floor"]), (["l1_geom"], ["brick_geom", "pad_a"])]
+    tasks, limits = specs(model, groups)
+    B = 6144
+    q, tg = inputs(model, dm, B, 17, near=("l1_geom", "l2_geom", "l3_geom"))
+    staged = DeviceProblem(dm, tasks, limits)
+    assert staged.staged
+    v_s, st_s = staged.solve(q, tg, DT, DAMPING)
+    (v_g, st_g), general = solve_general(dm, tasks, limits, q, tg)
+    assert int(st_g.abs().sum()) == 0 and torch.equal(st_s, st_g)
+    d = (v_s - v_g).abs().amax(dim=1)
+    print("staged vs general with link capsules: max |dv| =", float(d.max()))
+    assert float(d.max()) <= 1e-9
+    P, c, G, h = general.build_qp(q, tg, DT, DAMPING)
+    npair = len(limits[2]["index"]) // 2
+    in_range = torch.isfinite(h[:, -npair:]).sum(dim=1)
+    os.environ["MK_NO_GENERAL_STAGE"] = "1"
+    try:
+        v_l, st_l = staged.solve(q, tg, DT, DAMPING)
+    finally:
+        del os.environ["MK_NO_GENERAL_STAGE"]
+    left = st_l != 0
+    print("rows in range per problem:", torch.bincount(in_range).tolist(), "left to the general kernel:", int(left.sum()))
+    assert float((in_range > 0).double().mean()) > 0.3
+    assert not bool((left & (in_range == 0)).any())
+    assert int(left.sum()) <= B // 50
+    free = solve_general(dm, tasks, limits[:2], q, tg)[0][0]
+    binding = ((free - v_g).abs().amax(dim=1) > 1e-6) & ~left
+    print("finished by the lane stage with a binding row:", int(binding.sum()))
+    assert int(binding.sum()) > 100
+    # a few of them end to end against the numpy restatement
+    qn, tn, vn = q.cpu().numpy(), tg.cpu().numpy(), v_s.cpu().numpy()
+    for i in torch.nonzero(binding)[:12, 0].tolist():
+        cfg = o.Configuration(model, qn[i])
+        otasks = [o.FrameTask("tool", "site", 1.0, 1.0, 1.0, 0.5, tn[i, :7]),
+                  o.RelativeFrameTask("tool", "site", "rail", "body", 0.5, 0.2, 0.7, 0.0, tn[i, 7:]),
+                  o.PostureTask(np.where(np.arange(model.nv) < 7, 0.05, 0.0), model.qpos0.copy())]
+        olimits = [o.ConfigurationLimit(model, gain=0.9), o.VelocityLimit(model, {k: np.atleast_1d(x) for k, x in VEL.items()}),
+                   o.CollisionAvoidanceLimit(model, groups, 0.7, 0.004, 0.02, 1e-3)]
+        vr = o.solve_ik(cfg, otasks, DT, damping=DAMPING, limits=olimits)
+        np.testing.assert_allclose(vn[i], vr, rtol=0, atol=1e-8, err_msg=f"problem {i}")

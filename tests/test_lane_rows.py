@@ -71,6 +71,69 @@ def test_lane_rows_against_oracle():
     assert (nrows > 0).sum() >= n // 2 and n_binding >= 5, (nrows, n_binding)
 
 
+def test_lane_rows_with_geoms_on_inner_links():
+    """Capsules on links inside the task chain of a synthetic arm against a loose box, a pillar and
+    the floor: the rows' columns stop at the link's joint."""
+    import os
+    from mink_amd import _lib as L
+    from mink_amd.limits import CollisionAvoidanceLimit
+    from mink_amd.mjcf import load_mjcf
+    model = load_mjcf(os.path.join(os.path.dirname(os.path.abspath(__file__)), "models", "grip_arm.xml"))
+    groups = [(["l2_geom", "l3_geom"], ["brick_geom", "pillar", "floor"]), (["l1_geom"], ["brick_geom", "pad_a"])]
+    vel = {"lift": 0.4, "j1": 1.5, "j2": 1.5, "j3": 2.0, "j4": 2.5, "fa": 0.05, "fb": 1.0}
+    cost = np.where(np.arange(model.nv) < 7, 0.05, 0.0)
+    site = model.site_id("tool")
+    tasks = [dict(type=L.TASK_FRAME, frame_type=L.FRAME_TYPES["site"], frame_id=site, cost=np.ones(6), gain=1.0, lm_damping=0.5),
+             dict(type=L.TASK_RELATIVE_FRAME, frame_type=L.FRAME_TYPES["site"], frame_id=site, root_type=L.FRAME_TYPES["body"],
+                  root_id=model.body_id("rail"), cost=np.array([0.5, 0.5, 0.5, 0.2, 0.2, 0.2]), gain=0.7, lm_damping=0.0),
+             dict(type=L.TASK_POSTURE, cost=cost, target_q=model.qpos0.copy(), gain=1.0, lm_damping=0.0)]
+    limits = [dict(type=L.LIMIT_CONFIGURATION, gain=0.9, min_distance_from_limits=0.0),
+              dict(type=L.LIMIT_VELOCITY, index=[int(model.jnt_dofadr[model.joint_id(n)]) for n in vel], vmax=list(vel.values())),
+              CollisionAvoidanceLimit(model, groups, gain=0.7, minimum_distance_from_collisions=0.004,
+                                      collision_detection_distance=0.02, bound_relaxation=1e-3)._spec(model)]
+    rng = np.random.default_rng(12)
+    n = 40
+    q = np.tile(model.qpos0, (n, 1))
+    tg = np.zeros((n, 14))
+    adr = int(model.jnt_qposadr[model.joint_id("brick_free")])
+    links = ("l1_geom", "l2_geom", "l3_geom")
+    for i in range(n):
+        for j in range(7):
+            lo, hi = model.jnt_range[j]
+            q[i, j] = rng.uniform(lo + 0.1 * (hi - lo), hi - 0.1 * (hi - lo))
+        cfg = o.Configuration(model, q[i])
+        at = cfg.get_transform_frame_to_world(links[rng.integers(0, 3)], "geom")
+        d = rng.normal(size=3)
+        q[i, adr:adr + 3] = at[4:] + d / np.linalg.norm(d) * rng.uniform(0.05, 0.09)
+        qq = rng.normal(size=4)
+        q[i, adr + 3:adr + 7] = qq / np.linalg.norm(qq)
+        qs = q[i].copy()
+        qs[:7] += rng.uniform(-0.1, 0.1, 7)
+        c2 = o.Configuration(model, qs)
+        t_world = c2.get_transform_frame_to_world("tool", "site")
+        tg[i, :7] = t_world
+        tg[i, 7:] = o.se3_multiply(o.se3_inverse(c2.get_transform_frame_to_world("rail", "body")), t_world)
+    v, good, nrows = hs.solve_rows(model, tasks, limits, q, tg, 0.01, 1e-3)
+    n_binding = 0
+    for i in range(n):
+        otasks = [o.FrameTask("tool", "site", 1.0, 1.0, 1.0, 0.5, tg[i, :7]),
+                  o.RelativeFrameTask("tool", "site", "rail", "body", 0.5, 0.2, 0.7, 0.0, tg[i, 7:]),
+                  o.PostureTask(cost, model.qpos0.copy())]
+        coll = o.CollisionAvoidanceLimit(model, groups, 0.7, 0.004, 0.02, 1e-3)
+        base = [o.ConfigurationLimit(model, gain=0.9), o.VelocityLimit(model, {k: np.atleast_1d(x) for k, x in vel.items()})]
+        cfg = o.Configuration(model, q[i])
+        vr = o.solve_ik(cfg, otasks, 0.01, damping=1e-3, limits=base + [coll])
+        h = coll.inequalities(cfg, 0.01)[1]
+        assert nrows[i] == int(np.isfinite(h).sum()), (i, nrows[i], h)
+        if not good[i]:
+            continue
+        np.testing.assert_allclose(v[i], vr, rtol=0, atol=2e-9, err_msg=f"problem {i}, rows {nrows[i]}")
+        v0 = o.solve_ik(cfg, otasks, 0.01, damping=1e-3, limits=base)
+        n_binding += int(np.abs(v0 - vr).max() > 1e-7)
+    assert good.sum() >= n - 2
+    assert (nrows > 0).sum() >= n // 3 and n_binding >= 5, (nrows, n_binding)
+
+
 def test_box_box_search_against_exhaustive_enumeration():
     """The device searches the closest points of two separated boxes over the vertex-box candidates
     and one edge pair (the support edges of the widest cross-product axis); the numpy restatement
