@@ -286,3 +286,59 @@ def test_staged_solve_with_geoms_on_inner_links(env):
                    o.CollisionAvoidanceLimit(model, groups, 0.7, 0.004, 0.02, 1e-3)]
         vr = o.solve_ik(cfg, otasks, DT, damping=DAMPING, limits=olimits)
         np.testing.assert_allclose(vn[i], vr, rtol=0, atol=1e-8, err_msg=f"problem {i}")
+
+
+def test_staged_solve_with_mesh_geoms_on_tidybot_arm_links():
+    """TidyBot's own mesh geoms on inner links of the arm against the cube, the floor and the arm's
+    base: screened by bounding spheres on the structured kernel's chain poses, rows and solve by
+    the general kernel."""
+    from mink_amd import workloads as W
+    from mink_amd.mjcf import load_builtin
+    model = load_builtin("tidybot_cube")
+    dm = DeviceModel(model, torch.device("cuda:0"))
+    by_body = {model.body_names[model.geom_bodyid[g]]: g for g in range(model.ngeom)
+               if model.geom_dataid[g] >= 0 and (model.geom_contype[g] or model.geom_conaffinity[g])}
+    links = [by_body[n] for n in ("forearm_link", "spherical_wrist_2_link", "bracelet_link")]
+    coll = CollisionAvoidanceLimit(model, [(links, ["cube_geom", "floor", by_body["gen3/base_link"]])], gain=0.85,
+                                   minimum_distance_from_collisions=0.01, collision_detection_distance=0.06)
+    limits = W.limit_specs(model, True) + [coll._spec(model)]
+    tasks = W.task_specs(model, False)
+    npair = len(limits[-1]["index"]) // 2
+    assert npair == 9
+    rng = np.random.default_rng(31)
+    B = 2048
+    q = W.sample_q(model, rng, B)
+    q[:, 4] = rng.uniform(0.8, 2.0, B)           # fold the arm towards its base
+    q[:, 6] = rng.uniform(-2.4, -1.2, B)
+    adr = int(model.jnt_qposadr[model.joint_id("interactive_obj_freejoint")])
+    tq = torch.tensor(q, device=dm.device)
+    at = dm.frame_pose(tq, L.FRAME_TYPES["geom"], links[1])[:, 4:].cpu().numpy()
+    d = rng.normal(size=(B, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    near = rng.uniform(size=B) < 0.5
+    q[near, adr:adr + 3] = (at + d * rng.uniform(0.08, 0.2, (B, 1)))[near]
+    tq = torch.tensor(q, device=dm.device)
+    tg = dm.frame_pose(torch.tensor(W.sample_q(model, rng, B), device=dm.device), L.FRAME_TYPES["site"],
+                       model.site_id("pinch_site")).contiguous()
+    staged = DeviceProblem(dm, tasks, limits)
+    assert staged.staged
+    v_s, st_s = staged.solve(tq, tg, DT, DAMPING)
+    (v_g, st_g), general = solve_general(dm, tasks, limits, tq, tg)
+    assert torch.equal(st_s, st_g)
+    ok = st_g == 0
+    assert float(ok.double().mean()) > 0.9       # (deep penetrations of the folded arm are infeasible: both say so)
+    d = (v_s - v_g)[ok].abs().amax(dim=1)
+    print("staged vs general with mesh geoms on arm links: max |dv| =", float(d.max()))
+    assert float(d.max()) <= 1e-9
+    P, c, G, h = general.build_qp(tq, tg, DT, DAMPING)
+    in_range = torch.isfinite(h[:, -npair:]).any(dim=1)
+    os.environ["MK_NO_GENERAL_STAGE"] = "1"
+    try:
+        _, st_l = staged.solve(tq, tg, DT, DAMPING)
+    finally:
+        del os.environ["MK_NO_GENERAL_STAGE"]
+    left = (st_l & (1 << 30)) != 0
+    print("rows in range:", int(in_range.sum()), "left to the general kernel:", int(left.sum()), "of", B)
+    assert int(in_range.sum()) > B // 10
+    assert bool(left[in_range].all())            # the screen never drops a problem with a row in range
+    assert int((~left).sum()) > B // 10          # and it does spare the general kernel a share of the batch
