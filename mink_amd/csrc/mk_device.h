@@ -101,10 +101,10 @@ struct MkFusedDesc {
 // keeps, a pair without a closed form -- ellipsoid, cylinder, mesh --, no convergence of its dual
 // iteration).
 constexpr int MK_LANE_ROWS = 4;    // general rows per problem in the lane-per-problem solve
-constexpr int MK_MAX_CBODY = 6;    // bodies carrying collision geoms
+constexpr int MK_MAX_CBODY = 10;    // bodies carrying collision geoms
 constexpr int MK_MAX_CSEG = 4;     // 1-dof joints between the chain and such a body
 constexpr int MK_MAX_CGEOM = 12;
-constexpr int MK_MAX_CPAIR = 16;
+constexpr int MK_MAX_CPAIR = 40;
 enum { MK_CB_WORLD = 0, MK_CB_TIP = 1, MK_CB_FREE = 2 };   // TIP: carried by a joint frame of the chain
 constexpr int32_t MK_STATUS_PENDING = 1 << 30;   // in a status entry: the general kernel still has to solve it
 

@@ -289,22 +289,24 @@ def test_staged_solve_with_geoms_on_inner_links(env):
 
 
 def test_staged_solve_with_mesh_geoms_on_tidybot_arm_links():
-    """TidyBot's own mesh geoms on inner links of the arm against the cube, the floor and the arm's
-    base: screened by bounding spheres on the structured kernel's chain poses, rows and solve by
+    """TidyBot's own mesh geoms on the last five links of the arm against those of the mobile base,
+    the cube and the floor: screened by bounding spheres on the structured kernel's chain poses, rows and solve by
     the general kernel."""
     from mink_amd import workloads as W
     from mink_amd.mjcf import load_builtin
     model = load_builtin("tidybot_cube")
     dm = DeviceModel(model, torch.device("cuda:0"))
-    by_body = {model.body_names[model.geom_bodyid[g]]: g for g in range(model.ngeom)
-               if model.geom_dataid[g] >= 0 and (model.geom_contype[g] or model.geom_conaffinity[g])}
-    links = [by_body[n] for n in ("forearm_link", "spherical_wrist_2_link", "bracelet_link")]
-    coll = CollisionAvoidanceLimit(model, [(links, ["cube_geom", "floor", by_body["gen3/base_link"]])], gain=0.85,
+    coll_geoms = [g for g in range(model.ngeom)
+                  if model.geom_dataid[g] >= 0 and (model.geom_contype[g] or model.geom_conaffinity[g])]
+    arm = [g for g in coll_geoms if model.geom_bodyid[g] in (6, 7, 8, 9, 10)]       # forearm ... gripper base
+    base = [g for g in coll_geoms if model.geom_bodyid[g] in (1, 2)][:5]            # mobile base, arm base
+    links = arm
+    coll = CollisionAvoidanceLimit(model, [(arm, base + ["cube_geom", "floor"])], gain=0.85,
                                    minimum_distance_from_collisions=0.01, collision_detection_distance=0.06)
     limits = W.limit_specs(model, True) + [coll._spec(model)]
     tasks = W.task_specs(model, False)
     npair = len(limits[-1]["index"]) // 2
-    assert npair == 9
+    assert npair == 35          # 12 geoms on 9 bodies
     rng = np.random.default_rng(31)
     B = 2048
     q = W.sample_q(model, rng, B)
