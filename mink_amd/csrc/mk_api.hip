@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/mink_amd.h"
@@ -22,9 +23,9 @@ hipError_t mk_fused_launch_step(int nc, const MkFusedDesc* d_desc, int nq, const
                                 hipStream_t stream);
 hipError_t mk_fused_launch_step_ext(int nc, const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nq, const double* q,
                                     const double* targets, int target_stride, double dt, double damping, int B,
-                                    double* v, int32_t* status, hipStream_t stream, int32_t* iters = nullptr,
-                                    double* err = nullptr, int it = 0, int max_iters = 0, double pos_tol = 0.0,
-                                    double ori_tol = 0.0);
+                                    double* v, int32_t* status, hipStream_t stream, int screen_doubles,
+                                    int32_t* iters = nullptr, double* err = nullptr, int it = 0, int max_iters = 0,
+                                    double pos_tol = 0.0, double ori_tol = 0.0);
 hipError_t mk_fused_launch_rows(int nc, const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nv, const double* q,
                                 const double* targets, int target_stride, double dt, double damping, int B, double* v,
                                 int32_t* status, hipStream_t stream);
@@ -561,6 +562,7 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
     return body_slot[gb] = X->ncbody++;
   };
   std::vector<int> geom_slot(m.ngeom, -1);
+  int n_orient = 0;
   auto coll_geom = [&](int g) -> int {
     if (geom_slot[g] >= 0) return geom_slot[g];
     if (X->ncgeom >= MK_MAX_CGEOM) { why = "too many collision geoms"; return -1; }
@@ -574,6 +576,8 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
     memcpy(G.size, &m.geom_size[3 * g], 24);
     const double* sz = G.size;
     G.bc[0] = G.bc[1] = G.bc[2] = 0.0;
+    G.oslot = -1;
+    if (G.type == 0 || G.type == 6) G.oslot = n_orient++;
     switch (G.type) {
       case 2: G.rbound = sz[0]; break;
       case 3: G.rbound = sz[0] + sz[1]; break;
@@ -611,6 +615,23 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
       P.gain = L.gain;
       P.relax = L.bound_relaxation;
     }
+  }
+  X->norient = n_orient;
+  // geoms in the order of their bodies, so that a body names its geoms as a range
+  std::vector<int> order(X->ncgeom), where(X->ncgeom);
+  for (int g = 0; g < X->ncgeom; ++g) order[g] = g;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return X->cgeom[a].body < X->cgeom[b].body; });
+  MkCollGeom sorted[MK_MAX_CGEOM];
+  for (int g = 0; g < X->ncgeom; ++g) { sorted[g] = X->cgeom[order[g]]; where[order[g]] = g; }
+  for (int b = 0; b < X->ncbody; ++b) X->cbody[b].g0 = X->cbody[b].ng = 0;
+  for (int g = 0; g < X->ncgeom; ++g) {
+    X->cgeom[g] = sorted[g];
+    MkCollBody& CB = X->cbody[sorted[g].body];
+    if (CB.ng++ == 0) CB.g0 = g;
+  }
+  for (int k = 0; k < X->ncpair; ++k) {
+    X->cpair[k].g1 = where[X->cpair[k].g1];
+    X->cpair[k].g2 = where[X->cpair[k].g2];
   }
   return true;
 }
@@ -1122,7 +1143,8 @@ int mk_solve_ik_batch(const mk_problem* p, const double* d_q, const double* d_ta
     // it keeps, no convergence) through the general kernel;
     // both overwrite velocity and status of the problems they finish.
     MK_HIP(mk_fused_launch_step_ext(p->nc_kernel, p->d_fused, p->d_ext, p->info.nq, d_q, d_targets, p->info.target_stride,
-                                    dt, damping, B, d_v, d_status, static_cast<hipStream_t>(stream)));
+                                    dt, damping, B, d_v, d_status, static_cast<hipStream_t>(stream),
+                                    3 * p->h_ext.ncgeom + 4 * p->h_ext.norient));
     const bool lane_rows = getenv("MK_NO_LANE_ROWS") == nullptr;   // tuning / tests: skip the middle stage
     if (p->h_ext.ncpair > 0 && lane_rows)
       MK_HIP(mk_fused_launch_rows(p->nc_kernel, p->d_fused, p->d_ext, p->info.nv, d_q, d_targets, p->info.target_stride,
@@ -1169,7 +1191,8 @@ int mk_solve_ik_iterate_batch(const mk_problem* p, double* d_q, const double* d_
     MK_HIP(hipMemsetAsync(d_err, 0, sizeof(double) * (size_t)B * 6, st));
     for (int it = 0; it <= max_iters; ++it) {
       MK_HIP(mk_fused_launch_step_ext(p->nc_kernel, p->d_fused, p->d_ext, p->info.nq, d_q, d_targets, p->info.target_stride,
-                                      dt, damping, B, d_v, d_status, st, d_iters, d_err, it, max_iters, pos_tol, ori_tol));
+                                      dt, damping, B, d_v, d_status, st, 3 * p->h_ext.ncgeom + 4 * p->h_ext.norient, d_iters,
+                                      d_err, it, max_iters, pos_tol, ori_tol));
       if (it == max_iters) break;
       if (p->h_ext.ncpair > 0) {
         MK_HIP(mk_fused_launch_rows(p->nc_kernel, p->d_fused, p->d_ext, p->info.nv, d_q, d_targets, p->info.target_stride, dt,

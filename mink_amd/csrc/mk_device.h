@@ -103,7 +103,7 @@ struct MkFusedDesc {
 constexpr int MK_LANE_ROWS = 4;    // general rows per problem in the lane-per-problem solve
 constexpr int MK_MAX_CBODY = 10;    // bodies carrying collision geoms
 constexpr int MK_MAX_CSEG = 4;     // 1-dof joints between the chain and such a body
-constexpr int MK_MAX_CGEOM = 12;
+constexpr int MK_MAX_CGEOM = 24;
 constexpr int MK_MAX_CPAIR = 40;
 enum { MK_CB_WORLD = 0, MK_CB_TIP = 1, MK_CB_FREE = 2 };   // TIP: carried by a joint frame of the chain
 constexpr int32_t MK_STATUS_PENDING = 1 << 30;   // in a status entry: the general kernel still has to solve it
@@ -116,6 +116,7 @@ struct MkCollSeg {        // like MkSegC: fixed transform, then motion about / a
 struct MkCollBody {
   int32_t kind, nseg, free_qadr, free_dofadr;
   int32_t slot, pad0;     // MK_CB_TIP: the chain slot whose joint frame carries the body (nc - 1: the last one)
+  int32_t g0, ng;         // its geoms: cgeom[g0 .. g0 + ng)
   MkCollSeg seg[MK_MAX_CSEG];
   double tq[4], tp[3];    // fixed transform behind the last joint (WORLD: the world pose)
   double pad2;
@@ -124,7 +125,8 @@ struct MkCollGeom {
   int32_t body, type;     // index into cbody, MuJoCo geom type
   double lq[4], lp[3];    // pose in the body frame
   double size[3], rbound; // rbound: radius of a bounding sphere about bc
-  double bc[3], pad;      // centre of the bounding sphere in the geom frame (meshes; 0 otherwise)
+  double bc[3];           // centre of the bounding sphere in the geom frame (meshes; 0 otherwise)
+  int32_t oslot, pad;     // planes and boxes: index among the oriented geoms (-1 otherwise)
 };
 struct MkCollPair {
   int32_t g1, g2;         // indices into cgeom, ordered by geom type
@@ -133,7 +135,7 @@ struct MkCollPair {
 };
 struct MkFusedExt {
   int32_t has_rel, rel_slot, rel_target_off, ncbody;
-  int32_t ncgeom, ncpair, pad0, pad1;
+  int32_t ncgeom, ncpair, norient, pad1;   // norient: planes and boxes among the geoms
   double rel_cost[6], rel_gain, rel_lm;
   double rel_xq[4], rel_xp[3], pad2;   // root frame in the frame the pass carries at rel_slot
   MkCollBody cbody[MK_MAX_CBODY];

@@ -722,13 +722,14 @@ MK_DEV PoseQT chain_frame_pose(const MkFusedDesc* __restrict__ D, const double* 
 // collision row there either.  (Qw, tw) is the world pose of the task frame, `row` the
 // lane's q.
 MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const double* row,
-                               Q4 Qw, V3 tw) {
+                               Q4 Qw, V3 tw, double* scr, int ss) {
   // frame behind the chain's last joint: task frame o post^-1
   const Q4 postq = Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]};
   PoseQT tip;
   tip.q = qmul(Qw, qconj(postq));
   tip.t = tw - qrot(tip.q, v3(D->post_pos[0], D->post_pos[1], D->post_pos[2]));
-  PoseQT gp[MK_MAX_CGEOM];
+  // per geom the world centre of its bounding sphere (element 3 g + c of the lane's scratch column,
+  // scr[e * ss]); behind them the orientation of the planes and boxes (4 each, by G.oslot)
   const int nb = X->ncbody, ng = X->ncgeom;
   for (int b = 0; b < nb; ++b) {
     const MkCollBody& CB = X->cbody[b];
@@ -749,11 +750,15 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
       p.q = qnormalize(Q4{f[3], f[4], f[5], f[6]});
     }
     p = pose_then(p, Q4{CB.tq[0], CB.tq[1], CB.tq[2], CB.tq[3]}, v3(CB.tp[0], CB.tp[1], CB.tp[2]));
-#pragma unroll
-    for (int g = 0; g < MK_MAX_CGEOM; ++g) {
-      if (g < ng && X->cgeom[g].body == b) {
-        const MkCollGeom& G = X->cgeom[g];
-        gp[g] = pose_then(p, Q4{G.lq[0], G.lq[1], G.lq[2], G.lq[3]}, v3(G.lp[0], G.lp[1], G.lp[2]));
+    for (int g = CB.g0; g < CB.g0 + CB.ng; ++g) {
+      const MkCollGeom& G = X->cgeom[g];
+      const PoseQT w = pose_then(p, Q4{G.lq[0], G.lq[1], G.lq[2], G.lq[3]}, v3(G.lp[0], G.lp[1], G.lp[2]));
+      const V3 c = w.t + qrot(w.q, v3(G.bc[0], G.bc[1], G.bc[2]));
+      double* sc = scr + 3 * g * ss;
+      sc[0] = c.x; sc[ss] = c.y; sc[2 * ss] = c.z;
+      if (G.oslot >= 0) {
+        double* so = scr + (3 * ng + 4 * G.oslot) * ss;
+        so[0] = w.q.w; so[ss] = w.q.x; so[2 * ss] = w.q.y; so[3 * ss] = w.q.z;
       }
     }
   }
@@ -762,18 +767,21 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
   for (int k = 0; k < np; ++k) {
     const int g1 = X->cpair[k].g1, g2 = X->cpair[k].g2;
     const double d_detect = X->cpair[k].d_detect;
-    PoseQT a = gp[0], b = gp[0];
-#pragma unroll
-    for (int g = 0; g < MK_MAX_CGEOM; ++g) {   // register arrays: select, do not index
-      if (g == g1) a = gp[g];
-      if (g == g2) b = gp[g];
-    }
     const MkCollGeom& G1 = X->cgeom[g1];
     const MkCollGeom& G2 = X->cgeom[g2];
+    // centres of the bounding spheres (the geom centre but for meshes); orientations where kept
+    const double *s1 = scr + 3 * g1 * ss, *s2 = scr + 3 * g2 * ss;
+    const V3 ac = v3(s1[0], s1[ss], s1[2 * ss]), bcw = v3(s2[0], s2[ss], s2[2 * ss]);
+    PoseQT a = PoseQT{Q4{1, 0, 0, 0}, ac}, b = PoseQT{Q4{1, 0, 0, 0}, bcw};
+    if (G1.oslot >= 0) {
+      const double* so = scr + (3 * ng + 4 * G1.oslot) * ss;
+      a.q = Q4{so[0], so[ss], so[2 * ss], so[3 * ss]};
+    }
+    if (G2.oslot >= 0) {
+      const double* so = scr + (3 * ng + 4 * G2.oslot) * ss;
+      b.q = Q4{so[0], so[ss], so[2 * ss], so[3 * ss]};
+    }
     double lower;
-    // centres of the bounding spheres (off the geom centre for meshes only)
-    const V3 ac = a.t + qrot(a.q, v3(G1.bc[0], G1.bc[1], G1.bc[2]));
-    const V3 bcw = b.t + qrot(b.q, v3(G2.bc[0], G2.bc[1], G2.bc[2]));
     if (G1.type == 0) {   // plane: height of the other geom's centre minus its extent along the normal
       const M3 R1 = q2m(a.q);
       const V3 n = v3(R1.m[2], R1.m[5], R1.m[8]);
@@ -1443,7 +1451,8 @@ __global__ MK_KERNEL_ATTR void fused_step_ext_kernel(const MkFusedDesc* __restri
   }
   bool bad = rest_nonfinite(D, row);
   // collision screen first: it reads the lane's q, which the solve consumes
-  const bool pending = X->ncpair > 0 && collision_in_range(D, X, row, Qw, tw);
+  // (its scratch is the lane's column of the region that holds H afterwards)
+  const bool pending = X->ncpair > 0 && collision_in_range(D, X, row, Qw, tw, hlds, 64);
   uint32_t act = 0u, upper = 0u;
   int status;
   if (X->has_rel) {
@@ -1935,10 +1944,11 @@ hipError_t mk_fused_launch_step(int nc, const MkFusedDesc* d_desc, int nq, const
 template <int NC>
 static hipError_t launch_step_ext(const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nq, const double* q,
                                   const double* targets, int target_stride, double dt, double damping, int B, double* v,
-                                  int32_t* status, hipStream_t stream, int32_t* iters, double* err, int it,
-                                  int max_iters, double pos_tol, double ori_tol) {
+                                  int32_t* status, hipStream_t stream, int screen_doubles, int32_t* iters, double* err,
+                                  int it, int max_iters, double pos_tol, double ori_tol) {
   const int blocks = (B + 63) / 64;
-  const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
+  // per lane: its q, and H or (before it) the scratch of the collision screen
+  const size_t lds = (size_t)64 * ((nq | 1) + std::max(NC * (NC + 1) / 2, screen_doubles)) * sizeof(double);
   if (hipError_t e = allow_lds<fused_step_ext_kernel<NC>>(lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(fused_step_ext_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, d_ext, q, targets,
                      target_stride, dt, damping, B, v, status, iters, err, it, max_iters, pos_tol, ori_tol);
@@ -1947,13 +1957,13 @@ static hipError_t launch_step_ext(const MkFusedDesc* d_desc, const MkFusedExt* d
 
 hipError_t mk_fused_launch_step_ext(int nc, const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nq, const double* q,
                                     const double* targets, int target_stride, double dt, double damping, int B,
-                                    double* v, int32_t* status, hipStream_t stream, int32_t* iters, double* err, int it,
-                                    int max_iters, double pos_tol, double ori_tol) {
+                                    double* v, int32_t* status, hipStream_t stream, int screen_doubles, int32_t* iters,
+                                    double* err, int it, int max_iters, double pos_tol, double ori_tol) {
   switch (nc) {
 #define MK_CASE(N)                                                                                                  \
   case N:                                                                                                           \
-    return launch_step_ext<N>(d_desc, d_ext, nq, q, targets, target_stride, dt, damping, B, v, status, stream, iters, \
-                              err, it, max_iters, pos_tol, ori_tol);
+    return launch_step_ext<N>(d_desc, d_ext, nq, q, targets, target_stride, dt, damping, B, v, status, stream,       \
+                              screen_doubles, iters, err, it, max_iters, pos_tol, ori_tol);
     MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
 #undef MK_CASE
     default: return hipErrorInvalidValue;

@@ -299,14 +299,14 @@ def test_staged_solve_with_mesh_geoms_on_tidybot_arm_links():
     coll_geoms = [g for g in range(model.ngeom)
                   if model.geom_dataid[g] >= 0 and (model.geom_contype[g] or model.geom_conaffinity[g])]
     arm = [g for g in coll_geoms if model.geom_bodyid[g] in (6, 7, 8, 9, 10)]       # forearm ... gripper base
-    base = [g for g in coll_geoms if model.geom_bodyid[g] in (1, 2)][:5]            # mobile base, arm base
+    base = [g for g in coll_geoms if model.geom_bodyid[g] in (1, 2)]                # mobile base, arm base
     links = arm
     coll = CollisionAvoidanceLimit(model, [(arm, base + ["cube_geom", "floor"])], gain=0.85,
                                    minimum_distance_from_collisions=0.01, collision_detection_distance=0.06)
     limits = W.limit_specs(model, True) + [coll._spec(model)]
     tasks = W.task_specs(model, False)
     npair = len(limits[-1]["index"]) // 2
-    assert npair == 35          # 12 geoms on 9 bodies
+    assert npair == 40          # 13 geoms on 9 bodies
     rng = np.random.default_rng(31)
     B = 2048
     q = W.sample_q(model, rng, B)
