@@ -18,7 +18,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 from mink_amd import _lib as L
 from mink_amd import workloads as W
-from mink_amd.engine import DeviceModel, DeviceProblem
+from mink_amd.engine import DeviceModel, DeviceProblem, qp_solve
 from mink_amd.mjcf import load_builtin
 from oracle import c_oracle as co
 
@@ -73,9 +73,10 @@ def main():
     assert co.available(), "build the C oracle first (python -c 'import __graft_entry__ as g; g.build()')"
     print(f"# soak: fused kernels against the C restatement, {TRIALS} random parameter sets x {B} problems\n")
     print("| # | model | dt | damping | frame gain / lm | posture | damping task | vel limit | cfg gain | targets | "
-          "max abs dv (1 step) | rel. | max abs v | max abs dq (<= 10-step loop) | rel. | solve counts differ | status differ |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+          "max abs dv (1 step) | rel. | max abs v | max abs dq (<= 10-step loop) | rel. | solve counts differ | status differ | general kernels vs fused: rel. dv | status differ |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     worst_v, worst_q, bad = 0.0, 0.0, 0
+    worst_d = 0.0
     worst_well = [0.0, 0.0]   # parameter sets with damping >= 1e-3 or a Levenberg-Marquardt term
     t0 = time.time()
     for trial in range(TRIALS):
@@ -105,6 +106,15 @@ def main():
         # relative to the size of the problem's own answer: with a vanishing damping and no
         # Levenberg-Marquardt term the Hessian is singular to working precision and |v| is unbounded
         rv = float((dvs.max(axis=1) / np.maximum(1.0, vmag)).max()) if ok.any() else 0.0
+        # the same step through the general kernels: dense build + dense dual-method QP
+        P, c, G, h = prob.build_qp(dq0, dtg, p["dt"], p["damping"])
+        xd, std = qp_solve(P, c, G, h)
+        okd = ok & (std.cpu().numpy() == 0)
+        dd = (np.abs(xd.cpu().numpy() / p["dt"] - v.cpu().numpy())[okd].max(axis=1) / np.maximum(1.0, np.abs(v_ref[okd]).max(axis=1))
+              if okd.any() else np.zeros(1))
+        rd = float(dd.max())
+        n_std = int((std.cpu().numpy() != st.cpu().numpy()).sum())
+        worst_d = max(worst_d, rd) if (p["damping"] >= 1e-3 or p["frame_lm"] > 0.0) else worst_d
         qg = dq0.clone()
         r = prob.iterate_(qg, dtg, p["dt"], p["damping"], 10, 1e-4, 1e-4)
         q_ref, it_ref, _, st2_ref = orc.iterate(q0, tg, p["dt"], p["damping"], 10, 1e-4, 1e-4, nthreads=THREADS)
@@ -122,11 +132,12 @@ def main():
         print(f"| {trial} | {name} | {p['dt']:.3g} | {p['damping']:.0e} | {p['frame_gain']:.2f} / {p['frame_lm']:.0e} | "
               f"{p['posture_cost'][3]:.0e} x {p['posture_gain']:.2f} | {p['with_damping_task']} | {p['with_velocity']} | "
               f"{p['cfg_gain']} | {'near' if p['near'] else 'far'} | {dv:.2e} | {rv:.1e} | {float(vmag.max()) if ok.any() else 0.0:.1e} | "
-              f"{dq:.2e} | {rq:.1e} | {n_it} | {n_st} |", flush=True)
+              f"{dq:.2e} | {rq:.1e} | {n_it} | {n_st} | {rd:.1e} | {n_std} |", flush=True)
     print(f"\nworst relative dv {worst_v:.3e}, worst relative dq {worst_q:.3e} (relative to max(1, |v|) of the problem / to "
           f"max(1, distance moved)); status mismatches {bad}; {TRIALS * B} problems in {time.time() - t0:.0f} s")
     print(f"\nparameter sets with damping >= 1e-3 or a Levenberg-Marquardt term on the frame task (what the callers use): "
-          f"worst absolute |dv| {worst_well[0]:.3e} rad/s, worst absolute |dq| {worst_well[1]:.3e}")
+          f"worst absolute |dv| {worst_well[0]:.3e} rad/s, worst absolute |dq| {worst_well[1]:.3e}; general kernels "
+          f"(mk_build_qp_batch + mk_qp_solve_batch) against the fused kernel on those sets: worst relative |dv| {worst_d:.3e}")
 
 
 if __name__ == "__main__":
