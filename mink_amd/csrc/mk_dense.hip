@@ -383,6 +383,11 @@ __device__ __attribute__((noinline)) bool invert_regs(double* M, int np, int n, 
 // quantities the step computes anyway.  Returns the status; lane i receives x_i.
 MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, double& x_out) {
   const int np = s.npad, na1 = s.na1;
+  // row `lane` of H itself, kept for the refinement passes at the end (P becomes H^-1 below)
+  double hrow[MK_MAX_NV];
+  if (lane < n) {
+    for (int j = 0; j < n; ++j) hrow[j] = s.P[lane * np + j];
+  }
   if (n <= 16) {
     if (!invert_regs<16>(s.P, np, n, lane)) return 3;
   } else if (n <= 24) {
@@ -632,6 +637,119 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
       __syncthreads();
     }
     if (failed) break;
+  }
+  // ---- refinement on the final active set ----
+  // The dual method reaches the optimum from the unconstrained minimiser through explicit
+  // inverses; when that minimiser lies many box widths outside the limits (small damping, no
+  // Levenberg-Marquardt term) the cancellation costs digits.  With A the final active set, two
+  // passes of iterative refinement on its KKT system -- residuals from H, c and the rows
+  // themselves, corrections through the same inverses,
+  //   r = H x + c + N u,  s = N'x - b,  du = (N'H^-1N)^-1 (s - N'H^-1 r),  dx = -H^-1 (r + N du)
+  // -- bring x back to working accuracy; active bounds are then met exactly.  A pass is kept
+  // only if the residuals it was computed from are smaller than those of the pass before (with
+  // a Hessian singular to working precision the inverses are too poor to refine anything).
+  if (status == 0) {
+    double x_prev = x, m_prev = INFINITY;
+    double hmax = lane < n ? hrow[lane] : 0.0;   // largest diagonal entry of H: x units -> gradient units
+    {
+      int idm = lane;
+      wave_argmax(hmax, idm);
+    }
+    for (int pass = 0; pass < 3; ++pass) {
+      if (lane < n) s.xs[lane] = x;
+      __syncthreads();
+      double r = 0.0;
+      if (lane < n) {
+        r = s.c[lane];
+        for (int j = 0; j < n; ++j) r += hrow[j] * s.xs[j];
+      }
+      for (int a = 0; a < na; ++a) {
+        const int id = s.act[a];
+        const double ua = s.u[a];
+        if (id < n) { if (lane == id) r += ua; }
+        else if (id < 2 * n) { if (lane == id - n) r -= ua; }
+        else if (lane < n) r += s.Gg[(id - 2 * n) * np + lane] * ua;
+      }
+      // lane a < na: residual of its own equation n_a'x = b_a
+      const int ida = lane < na ? s.act[lane] : 0;
+      const int ja = ida < n ? ida : (ida < 2 * n ? ida - n : 0);
+      double sres = 0.0;
+      {
+        const double xj = __shfl(x, ja), hj = __shfl(hi, ja), lj = __shfl(lo, ja);
+        if (lane < na) {
+          if (ida < n) sres = xj - hj;
+          else if (ida < 2 * n) sres = lj - xj;
+          else {
+            const double* g = s.Gg + (ida - 2 * n) * np;
+            sres = -s.hg[ida - 2 * n];
+            for (int j = 0; j < n; ++j) sres += g[j] * s.xs[j];
+          }
+        }
+      }
+      // the size of this x's residuals decides whether the pass that produced it is kept
+      double m = fmax(fabs(r), hmax * fabs(sres));
+      if (!(m == m)) m = INFINITY;
+      {
+        int idm = lane;
+        wave_argmax(m, idm);
+      }
+      if (!(m < m_prev)) {   // wave-uniform
+        x = x_prev;
+        break;
+      }
+      x_prev = x;
+      m_prev = m;
+      if (pass == 2) break;
+      if (lane < n) s.hin[lane] = r;
+      __syncthreads();
+      double w = 0.0;
+      if (lane < n) {
+        const double* hr = Hi + lane * np;
+        for (int j = 0; j < n; ++j) w += hr[j] * s.hin[j];
+        s.rr[lane] = w;
+      }
+      __syncthreads();
+      // its component of N'H^-1 r
+      double rhs = 0.0;
+      {
+        const double wj = __shfl(w, ja);
+        if (lane < na) {
+          if (ida < n) rhs = sres - wj;
+          else if (ida < 2 * n) rhs = sres + wj;
+          else {
+            const double* g = s.Gg + (ida - 2 * n) * np;
+            double sw = 0.0;
+            for (int j = 0; j < n; ++j) sw += g[j] * s.rr[j];
+            rhs = sres - sw;
+          }
+        }
+      }
+      double du = 0.0;
+      {
+        const double* mr = s.Minv + (lane < na ? lane : 0) * na1;
+        for (int b2 = 0; b2 < na; ++b2) du += mr[b2] * readlane_f64(rhs, b2);
+        if (lane >= na) du = 0.0;
+      }
+      bool small;
+      {
+        double acc = w;
+        const double* hc = s.HiN + (lane < n ? lane : 0);
+        for (int a = 0; a < na; ++a) acc += hc[a * np] * readlane_f64(du, a);
+        // a correction far below the size of x itself: x was accurate already, nothing to check
+        double dm = lane < n ? fabs(acc) : 0.0, xm = lane < n ? fabs(x) : 0.0;
+        int idm = lane;
+        wave_argmax(dm, idm);
+        idm = lane;
+        wave_argmax(xm, idm);
+        small = dm <= 1e-11 * xm;
+        if (lane < n) x -= acc;
+      }
+      if (small) break;   // wave-uniform
+      if (lane < na) s.u[lane] += du;
+      __syncthreads();
+    }
+    if (act_hi && fabs(x - hi) <= 1e-9 * fmax(1.0, fabs(hi))) x = hi;
+    if (act_lo && fabs(lo - x) <= 1e-9 * fmax(1.0, fabs(lo))) x = lo;
   }
   x_out = x;
 #if defined(MK_DENSE_COUNT_STEPS)
