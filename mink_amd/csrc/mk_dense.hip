@@ -640,8 +640,9 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
   }
   // ---- refinement on the final active set ----
   // The dual method reaches the optimum from the unconstrained minimiser through explicit
-  // inverses; when that minimiser lies many box widths outside the limits (small damping, no
-  // Levenberg-Marquardt term) the cancellation costs digits.  With A the final active set, two
+  // inverses (H^-1, and the Gram matrix of the active rows formed from it), so its error grows
+  // like cond(H)^2: 1e-4 relative at cond(H) ~ 1e6 (small damping, no Levenberg-Marquardt
+  // term).  With A the final active set, two
   // passes of iterative refinement on its KKT system -- residuals from H, c and the rows
   // themselves, corrections through the same inverses,
   //   r = H x + c + N u,  s = N'x - b,  du = (N'H^-1N)^-1 (s - N'H^-1 r),  dx = -H^-1 (r + N du)

@@ -252,3 +252,35 @@ def test_staged_relative_frame_without_collision(env):
         v_g, st_g = general.solve(q, tg, W.DT, W.DAMPING)
         assert int(st_s.abs().sum()) == 0 and int(st_g.abs().sum()) == 0
         assert float((v_s - v_g).abs().max()) <= 1e-9, (root_id, float((v_s - v_g).abs().max()))
+
+
+def test_general_kernels_on_a_stiff_problem_match_the_fused_kernel():
+    """damping = 1e-3 without a Levenberg-Marquardt term or posture cost, large frame costs, long
+    time step, velocity limits: an ill-conditioned H with the unconstrained minimiser well outside
+    the limits, where the dual method with its explicit inverses loses digits (1e-4 relative on
+    such a set) unless its answer is refined on the final active set.  Dense build + dense QP against the fused kernel, whose
+    answers satisfy the KKT conditions to 1e-12 on such problems."""
+    from mink_amd.engine import DeviceModel, DeviceProblem, qp_solve
+    model = load_builtin("mobile_kinova")
+    dm = DeviceModel(model, "cuda:0")
+    rng = np.random.default_rng(16)
+    tasks = [dict(type=L.TASK_FRAME, frame_type=L.FRAME_TYPES["site"], frame_id=model.site_id("pinch_site"),
+                  cost=np.array([6.0, 6.0, 6.0, 8.0, 8.0, 8.0]), gain=0.94, lm_damping=0.0),
+             dict(type=L.TASK_POSTURE, cost=np.zeros(model.nv), target_q=W.home_q(model), gain=1.0, lm_damping=0.0)]
+    prob = DeviceProblem(dm, tasks, W.limit_specs(model, True))
+    assert prob.fused
+    B, dt, damping = 4096, 0.05, 1e-3
+    q = dev(W.sample_q(model, rng, B))
+    tg = dm.frame_pose(dev(W.sample_q(model, rng, B)), 2, model.site_id("pinch_site"))
+    v, st = prob.solve(q, tg, dt, damping)
+    P, c, G, h = prob.build_qp(q, tg, dt, damping)
+    x, sd = qp_solve(P, c, G, h)
+    assert int(st.abs().sum()) == 0 and int(sd.abs().sum()) == 0
+    # what makes the set hard: the conditioning of H, and an unconstrained minimiser outside the box
+    cond = torch.linalg.cond(P)
+    x0 = torch.linalg.solve(P, -c[..., None])[..., 0]
+    out = x0.abs().amax(dim=1) / (v.abs().amax(dim=1) * dt)
+    print(f"cond(H) median {float(cond.median()):.2e} max {float(cond.max()):.2e}; |x0| / |x| median {float(out.median()):.1f} "
+          f"max {float(out.max()):.1f}; max |dv| {float((x / dt - v).abs().max()):.2e}")
+    assert float(cond.median()) > 1e5
+    assert float((x / dt - v).abs().max()) < 1e-8
