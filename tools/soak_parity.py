@@ -45,6 +45,9 @@ def draw(rng, name):
     p["with_velocity"] = bool(rng.integers(2))
     p["cfg_gain"] = float(rng.choice([0.5, 0.95, 1.0]))
     p["near"] = bool(rng.integers(2))
+    # Levenberg-Marquardt term on the posture task (rare in callers; its own path in the kernels), drawn
+    # from a stream of its own so that the other parameters of a set do not depend on it
+    p["posture_lm"] = float(np.random.default_rng([2025, int(rng.integers(1 << 30))]).choice([0.0, 0.0, 1e-2]))
     return p
 
 
@@ -52,8 +55,8 @@ def specs(model, p):
     tasks = [dict(type=L.TASK_FRAME, frame_type=L.FRAME_TYPES["site"], frame_id=model.site_id("pinch_site"),
                   cost=p["frame_cost"], gain=p["frame_gain"], lm_damping=p["frame_lm"]),
              dict(type=L.TASK_POSTURE, cost=p["posture_cost"], target_q=W.home_q(model), gain=p["posture_gain"],
-                  lm_damping=0.0)]
-    postures = [dict(cost=p["posture_cost"], target_q=W.home_q(model), gain=p["posture_gain"])]
+                  lm_damping=p["posture_lm"])]
+    postures = [dict(cost=p["posture_cost"], target_q=W.home_q(model), gain=p["posture_gain"], lm_damping=p["posture_lm"])]
     if p["with_damping_task"]:
         tasks.append(dict(type=L.TASK_POSTURE, cost=W.base_damping_cost(model), target_q=model.qpos0.copy(), gain=0.0,
                           lm_damping=0.0))
@@ -130,7 +133,7 @@ def main():
         if p["damping"] >= 1e-3 or p["frame_lm"] > 0.0:
             worst_well = [max(worst_well[0], dv), max(worst_well[1], dq)]
         print(f"| {trial} | {name} | {p['dt']:.3g} | {p['damping']:.0e} | {p['frame_gain']:.2f} / {p['frame_lm']:.0e} | "
-              f"{p['posture_cost'][3]:.0e} x {p['posture_gain']:.2f} | {p['with_damping_task']} | {p['with_velocity']} | "
+              f"{p['posture_cost'][3]:.0e} x {p['posture_gain']:.2f} lm {p['posture_lm']:.0e} | {p['with_damping_task']} | {p['with_velocity']} | "
               f"{p['cfg_gain']} | {'near' if p['near'] else 'far'} | {dv:.2e} | {rv:.1e} | {float(vmag.max()) if ok.any() else 0.0:.1e} | "
               f"{dq:.2e} | {rq:.1e} | {n_it} | {n_st} | {rd:.1e} | {n_std} |", flush=True)
     print(f"\nworst relative dv {worst_v:.3e}, worst relative dq {worst_q:.3e} (relative to max(1, |v|) of the problem / to "
