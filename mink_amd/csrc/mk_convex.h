@@ -128,7 +128,24 @@ MK_CVX bool cvx_closest_simplex(CvxSimplex& S) {
     S.lam[0] = l.a; S.lam[1] = l.b; S.lam[2] = l.c;
     return false;
   }
-  // tetrahedron: the faces the origin lies outside of, closest one wins (first on ties)
+  // tetrahedron: the faces the origin lies outside of, closest one wins (first on ties).
+  // Support points of two polytopes are often coplanar (four vertices of one face of A - B): the
+  // side tests of such a flat tetrahedron are decided by rounding, and "outside of no face" would
+  // be read as an overlap.  A tetrahedron whose fourth vertex lies within 1e-9 (sine of the
+  // angle) of a face's plane is therefore never "inside": all its faces are candidates.
+  bool flat = false;
+#define CVX_FLAT(I, J, K, L)                                                                          \
+  {                                                                                                   \
+    const V3 fa = S.w[I], fd = S.w[L];                                                                \
+    const V3 nrm = cross(S.w[J] - fa, S.w[K] - fa);                                                   \
+    const double sd = dot(fd - fa, nrm);                                                              \
+    flat |= sd * sd <= 1e-18 * dot(nrm, nrm) * dot(fd - fa, fd - fa);                                  \
+  }
+  CVX_FLAT(0, 1, 2, 3)
+  CVX_FLAT(0, 2, 3, 1)
+  CVX_FLAT(0, 3, 1, 2)
+  CVX_FLAT(1, 3, 2, 0)
+#undef CVX_FLAT
   bool found = false;
   double best = INFINITY;
   double lam[4] = {0.25, 0.25, 0.25, 0.25};
@@ -137,7 +154,7 @@ MK_CVX bool cvx_closest_simplex(CvxSimplex& S) {
     const V3 fa = S.w[I], fb = S.w[J], fc = S.w[K], fd = S.w[L];                      \
     const V3 nrm = cross(fb - fa, fc - fa);                                           \
     const double so = -dot(fa, nrm), sd = dot(fd - fa, nrm);                          \
-    if (so * sd < 0.0 || sd == 0.0) {                                                 \
+    if (flat || so * sd < 0.0 || sd == 0.0) {                                         \
       const Bary3 l = cvx_closest_triangle(fa, fb, fc);                               \
       const V3 p = l.a * fa + l.b * fb + l.c * fc;                                    \
       const double d2 = dot(p, p);                                                    \

@@ -124,12 +124,20 @@ def _closest_simplex(W):
         return _closest_segment(W[0], W[1]), False
     if n == 3:
         return _closest_triangle(W[0], W[1], W[2]), False
+    # a flat tetrahedron (four support points of one face of A - B) has side tests decided by
+    # rounding: it is never "inside", all its faces are candidates (as in mk_convex.h)
+    flat = False
+    for (i, j, k, l) in _TET_FACES:
+        a, d = W[i], W[l]
+        nrm = np.cross(W[j] - a, W[k] - a)
+        sd = (d - a) @ nrm
+        flat |= bool(sd * sd <= 1e-18 * (nrm @ nrm) * ((d - a) @ (d - a)))
     best, best_d2 = None, np.inf
     for (i, j, k, l) in _TET_FACES:
         a, b, c, d = W[i], W[j], W[k], W[l]
         nrm = np.cross(b - a, c - a)
         so, sd = -(a @ nrm), (d - a) @ nrm
-        if so * sd < 0.0 or sd == 0.0:          # the origin is on the outer side of this face
+        if flat or so * sd < 0.0 or sd == 0.0:          # the origin is on the outer side of this face
             lam3 = _closest_triangle(a, b, c)
             p = lam3[0] * a + lam3[1] * b + lam3[2] * c
             d2 = p @ p

@@ -90,6 +90,39 @@ def test_tidybot_mesh_pairs_rows_and_solve():
     assert bad < B // 3
 
 
+def test_flat_simplex_of_two_hulls_is_not_read_as_an_overlap():
+    """A configuration found by the sweep of tools/soak_convex.py: the support points of two hulls
+    (forearm link against the mobile base, 112 and 615 vertices, 13.6 cm apart) come to lie in one
+    face of A - B, the side tests of the flat tetrahedron are decided by rounding, and an iteration
+    that reads "outside of no face" as an overlap hands the pair to the penetration routine (it
+    answered 10.8 cm).  The oracle's distance is certified here by the gap of the two support
+    functions along its own normal (a lower bound on the distance that meets the upper bound)."""
+    from oracle import convex as cx
+    model = load_builtin("tidybot_cube")
+    q = np.array([[0.465577852256327, -0.3765540571560093, 2.852721046839582, 0.04701512218339454, 1.2332867368981812,
+                   3.290758645020128, -2.062057539750064, -0.2647664736747073, 1.4557156186351876, 1.3635213968518987,
+                   0, 0, 0, 0, 0, 0, 0, 0, 0.6, 0, 0, 1, 0, 0, 0]], dtype=np.float64)
+    g1, g2 = 9, 24
+    lim = o.CollisionAvoidanceLimit(model, [([g1], [g2])], collision_detection_distance=0.25,
+                                    minimum_distance_from_collisions=0.02)
+    assert lim.geom_id_pairs == [(g1, g2)]
+    d = o.Configuration(model, q[0]).data
+
+    def shape(g):
+        k = int(model.geom_dataid[g])
+        return dict(type=int(model.geom_type[g]), pos=np.asarray(d.geom_xpos[g], float),
+                    mat=np.asarray(d.geom_xmat[g], float).reshape(3, 3), size=np.asarray(model.geom_size[g], float),
+                    verts=model.mesh_vert[model.mesh_vertadr[k]:model.mesh_vertadr[k] + model.mesh_vertnum[k]])
+
+    A, Bm = shape(g1), shape(g2)
+    dist, pa, pb = cx.distance(A, Bm)
+    n = (pb - pa) / np.linalg.norm(pb - pa)
+    gap = cx.support(Bm, -n) @ n - cx.support(A, n) @ n
+    assert abs(dist - 0.13559789169) < 1e-10 and abs(gap - dist) < 1e-12
+    n_active, _, _ = compare_rows(model, lim, q)
+    assert n_active == 1
+
+
 def test_cylinders_and_ellipsoids():
     model = load_mjcf(os.path.join(HERE, "models", "convex_arm.xml"))
     lim = o.CollisionAvoidanceLimit(model, [(["upper_geom", "fore_geom", "hand_box", "hand_ball", "torso_geom"],
