@@ -222,6 +222,8 @@ MK_CVX bool cvx_gjk(int lane, const CvxShape& A, const CvxShape& B, double& dist
     for (int i = 0; i < 4; ++i)
       if (i < S.n && S.w[i].x == w.x && S.w[i].y == w.y && S.w[i].z == w.z) dup = true;
     if (dup) break;
+    const CvxSimplex S_old = S;
+    const V3 v_old = v;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       if (i == S.n) { S.w[i] = w; S.a[i] = a; S.b[i] = b; }
@@ -230,6 +232,15 @@ MK_CVX bool cvx_gjk(int lane, const CvxShape& A, const CvxShape& B, double& dist
     cvx_reduce(S);
     v = cvx_combine(S.w, S.lam, S.n);
     if (inside || dot(v, v) <= (CVX_GJK_TOUCH * scale) * (CVX_GJK_TOUCH * scale)) return true;
+    // The new simplex contains the old one, so its closest point cannot be farther.  When the new
+    // support point adds nothing but rounding (a needle triangle next to the converged edge) the
+    // region tests may say otherwise, and the iteration would alternate between the two states for
+    // good: the old state is the answer.
+    if (S_old.n > 0 && !(dot(v, v) < vv)) {
+      S = S_old;
+      v = v_old;
+      break;
+    }
   }
   pa = cvx_combine(S.a, S.lam, S.n);
   pb = cvx_combine(S.b, S.lam, S.n);

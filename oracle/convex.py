@@ -167,6 +167,7 @@ def gjk(A, B):
             break
         if any(np.array_equal(w, x) for x in W):
             break
+        old = (list(W), list(PA), list(PB), list(lam), v)
         W.append(w); PA.append(a); PB.append(b)
         lam, inside = _closest_simplex(W)
         keep = [i for i, l in enumerate(lam) if l > 0.0]
@@ -175,6 +176,11 @@ def gjk(A, B):
         v = sum(l * x for l, x in zip(lam, W))
         if inside or v @ v <= (GJK_TOUCH * scale) ** 2:
             return 0.0, None, None, True
+        # the new simplex contains the old one: a closest point that is not nearer is rounding in the
+        # region tests of a needle triangle, and the old state is the answer (as in mk_convex.h)
+        if old[0] and not (v @ v < vv):
+            W, PA, PB, lam, v = old
+            break
     pa = sum(l * x for l, x in zip(lam, PA))
     pb = sum(l * x for l, x in zip(lam, PB))
     return float(np.sqrt(v @ v)), pa, pb, False

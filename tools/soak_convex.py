@@ -32,8 +32,38 @@ def spec_of(lim):
                 collision_detection_distance=lim.collision_detection_distance, bound_relaxation=lim.bound_relaxation)
 
 
-def sweep(name, model, lim, q, dt=0.01, tol=1e-6):
+def certificate_misses(model, lim, q_row):
+    """Pairs in range on which the restatement's own answer is not optimal: the gap of the two support
+    functions along its normal (a lower bound on the distance) must meet the distance it reports."""
+    from oracle import convex as cx
+    from oracle import mjlite as mj
+    d = o.Configuration(model, q_row).data
+    misses = checked = 0
+    for g1, g2 in lim.geom_id_pairs:
+        if int(model.geom_type[g1]) == 0 or int(model.geom_type[g2]) == 0:
+            continue
+        fromto = np.zeros(6)
+        dist, fromto = mj.mj_geomDistance(model, d, g1, g2, lim.collision_detection_distance)
+        if not (0.0 < dist < lim.collision_detection_distance):
+            continue
+        sh = []
+        for g in (g1, g2):
+            s = dict(type=int(model.geom_type[g]), pos=np.asarray(d.geom_xpos[g], float),
+                     mat=np.asarray(d.geom_xmat[g], float).reshape(3, 3), size=np.asarray(model.geom_size[g], float))
+            if s["type"] == cx.MESH:
+                k = int(model.geom_dataid[g])
+                s["verts"] = model.mesh_vert[model.mesh_vertadr[k]:model.mesh_vertadr[k] + model.mesh_vertnum[k]]
+            sh.append(s)
+        n = (fromto[3:] - fromto[:3]) / np.linalg.norm(fromto[3:] - fromto[:3])
+        gap = cx.support(sh[1], -n) @ n - cx.support(sh[0], n) @ n - cx.radius(sh[0]) - cx.radius(sh[1])
+        checked += 1
+        misses += int(abs(gap - dist) > 1e-7)
+    return checked, misses
+
+
+def sweep(name, model, lim, q, dt=0.01, tol=1e-6, certify=True):
     bad = []
+    n_checked = n_miss = 0
     dm = DeviceModel(model, DEV)
     prob = DeviceProblem(dm, [], [spec_of(lim)])
     P, c, G, h = prob.build_qp(dev(q), None, dt, 1e-3)
@@ -44,6 +74,9 @@ def sweep(name, model, lim, q, dt=0.01, tol=1e-6):
     worst = None
     for b in range(len(q)):
         Gr, hr = lim.inequalities(o.Configuration(model, q[b]), dt)
+        if certify:
+            ck, ms = certificate_misses(model, lim, q[b])
+            n_checked, n_miss = n_checked + ck, n_miss + ms
         fin = np.isfinite(hr)
         both = fin & np.isfinite(h[b])
         pattern += int((fin != np.isfinite(h[b])).sum())
@@ -67,6 +100,9 @@ def sweep(name, model, lim, q, dt=0.01, tol=1e-6):
     print(f"{name}: {len(q)} configurations x {len(lim.geom_id_pairs)} pairs = {n_rows} rows, {n_active} in range, {n_pen} at the "
           f"relaxation bound; in-range pattern differs on {pattern} rows; max |dG| {dG:.2e} (configuration {worst[0] if worst else -1}, "
           f"geoms {pair}), max |dh| {dh:.2e}", flush=True)
+    if certify:
+        print(f"  separated pairs in range whose distance the restatement certifies (support-function gap along its normal "
+              f"= distance, to 1e-7): {n_checked - n_miss} of {n_checked}")
     print(f"  rows with |dG| > {tol:g}: {len(bad)}")
     for r in sorted(bad, key=lambda t: -t[2])[:25]:
         print(f"    configuration {r[0]} geoms {r[1]}: |dG| {r[2]:.2e}, distance gpu {r[3]:+.6f} oracle {r[4]:+.6f}, |G| gpu {r[5]:.3f} oracle {r[6]:.3f}")
@@ -99,6 +135,37 @@ def main():
     qq = rng.normal(size=(B, 4))
     q[:, 14:18] = qq / np.linalg.norm(qq, axis=1, keepdims=True)
     sweep("cylinders / ellipsoids", model, lim, q, tol=1e-4)
+    # closed-form pairs (plane / sphere / capsule / box) on the floating-base tree, the free object next to a geom
+    model = load_mjcf(os.path.join(ROOT, "tests", "models", "float_arm.xml"))
+    pairs = [("obj_geom", "shin_geom"), ("shin_geom", "bar_geom"), ("ground", "shin_geom"), ("obj_geom", "torso_geom"),
+             ("obj_geom", "fore_geom"), ("leg_geom", "obj_geom"), ("ground", "fore_geom"), ("torso_geom", "fore_geom"),
+             ("upper_geom", "bar_geom"), ("ground", "obj_geom"), ("shin_geom", "fore_geom"), ("bar_geom", "torso_geom"),
+             ("bar_geom", "fore_geom")]
+    lim = o.CollisionAvoidanceLimit(model, [([a], [b]) for a, b in pairs], collision_detection_distance=0.3,
+                                    minimum_distance_from_collisions=0.01)
+    q = np.tile(model.qpos0, (B, 1))
+    for j in range(model.njnt):
+        a, t = int(model.jnt_qposadr[j]), int(model.jnt_type[j])
+        if t == 0:
+            q[:, a:a + 3] += rng.uniform(-0.2, 0.2, (B, 3))
+            w = rng.normal(size=(B, 4))
+            q[:, a + 3:a + 7] = w / np.linalg.norm(w, axis=1, keepdims=True)
+        elif t == 1:
+            w = rng.normal(size=(B, 4))
+            q[:, a:a + 4] = w / np.linalg.norm(w, axis=1, keepdims=True)
+        else:
+            lo, hi = (model.jnt_range[j] if model.jnt_limited[j] else (-1.0, 1.0))
+            q[:, a] = rng.uniform(lo + 0.05, hi - 0.05, B)
+    # the free object next to one of the robot's geoms in most configurations
+    fa = int(model.jnt_qposadr[model.joint_id("obj_free")])
+    names = ["shin_geom", "torso_geom", "fore_geom", "leg_geom"]
+    for b in range(B):
+        if b % 5 == 4:
+            continue
+        c = o.Configuration(model, q[b]).data.geom_xpos[model.geom_id(names[b % 4])]
+        dvec = rng.normal(size=3)
+        q[b, fa:fa + 3] = c + dvec / np.linalg.norm(dvec) * rng.uniform(0.0, 0.25)
+    sweep("closed-form primitive pairs", model, lim, q, tol=1e-7, certify=False)
 
 
 if __name__ == "__main__":
