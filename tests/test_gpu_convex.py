@@ -123,6 +123,34 @@ def test_flat_simplex_of_two_hulls_is_not_read_as_an_overlap():
     assert n_active == 1
 
 
+def test_iteration_that_stops_improving_keeps_its_best_state():
+    """Second configuration found by the sweep: a cylinder (the post) against the hand's box, 1.89 cm
+    apart.  Next to the converged edge of the simplex a new support point adds only rounding, the
+    region tests of the needle triangle place the closest point in its interior (2.19 cm) and the
+    next step comes back to the edge: an iteration without the "no nearer, so stop" rule alternates
+    until its limit and answers with whichever state the limit fell on."""
+    from oracle import convex as cx
+    model = load_mjcf(os.path.join(HERE, "models", "convex_arm.xml"))
+    q = np.array([[0.09120999333720148, 0.042785596544025306, 0.6759032101083793, 0.8800319553123718, -0.3252792911446259,
+                   -0.22584473273315, -0.26216654454416033, 0.1675671275555356, 0.2639281790292487, -0.32887765798477103,
+                   0.2580108820272303, 0.07479242630156516, 0.011455947252039425, 0.25467128696568747, 0.6938206065779933,
+                   0.49744794258556063, -0.19642816824777673, -0.4822597692364161]])
+    g1, g2 = 1, 6
+    assert int(model.geom_type[g1]) == cx.CYLINDER and int(model.geom_type[g2]) == cx.BOX
+    lim = o.CollisionAvoidanceLimit(model, [([g1], [g2])], collision_detection_distance=0.5,
+                                    minimum_distance_from_collisions=0.01)
+    d = o.Configuration(model, q[0]).data
+    sh = [dict(type=int(model.geom_type[g]), pos=np.asarray(d.geom_xpos[g], float),
+               mat=np.asarray(d.geom_xmat[g], float).reshape(3, 3), size=np.asarray(model.geom_size[g], float))
+          for g in (g1, g2)]
+    dist, pa, pb = cx.distance(sh[0], sh[1])
+    n = (pb - pa) / np.linalg.norm(pb - pa)
+    gap = cx.support(sh[1], -n) @ n - cx.support(sh[0], n) @ n
+    assert abs(dist - 0.0189000266) < 1e-9 and abs(gap - dist) < 1e-9
+    n_active, _, _ = compare_rows(model, lim, q, atol=2e-5)
+    assert n_active == 1
+
+
 def test_cylinders_and_ellipsoids():
     model = load_mjcf(os.path.join(HERE, "models", "convex_arm.xml"))
     lim = o.CollisionAvoidanceLimit(model, [(["upper_geom", "fore_geom", "hand_box", "hand_ball", "torso_geom"],
