@@ -120,3 +120,15 @@ def test_collision_row_is_the_distance_gradient(which):
             assert abs(fd + G[k] @ v) < 2e-5 * max(1.0, np.abs(v).max()), (k, g1, g2, fd, -G[k] @ v)
             checked += 1
     assert checked >= 8
+
+
+@pytest.mark.parametrize("case", ["FLAT_SIMPLEX", "TWO_STATE_CYCLE"])
+def test_restatement_on_configurations_that_break_an_unguarded_gjk(case):
+    """The numpy twin on the two configurations of tests/convex_cases.py: the distance it reports is
+    optimal (support-function gap along its normal = distance)."""
+    import convex_cases as cc
+    c = getattr(cc, case)
+    model = cc.load_case_model(c)
+    dist, gap = cc.distance_and_certificate(model, c["q"], *c["geoms"])
+    assert abs(dist - c["distance"]) < 1e-9
+    assert abs(gap - dist) < 1e-9

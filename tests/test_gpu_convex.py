@@ -90,64 +90,20 @@ def test_tidybot_mesh_pairs_rows_and_solve():
     assert bad < B // 3
 
 
-def test_flat_simplex_of_two_hulls_is_not_read_as_an_overlap():
-    """A configuration found by the sweep of tools/soak_convex.py: the support points of two hulls
-    (forearm link against the mobile base, 112 and 615 vertices, 13.6 cm apart) come to lie in one
-    face of A - B, the side tests of the flat tetrahedron are decided by rounding, and an iteration
-    that reads "outside of no face" as an overlap hands the pair to the penetration routine (it
-    answered 10.8 cm).  The oracle's distance is certified here by the gap of the two support
-    functions along its own normal (a lower bound on the distance that meets the upper bound)."""
-    from oracle import convex as cx
-    model = load_builtin("tidybot_cube")
-    q = np.array([[0.465577852256327, -0.3765540571560093, 2.852721046839582, 0.04701512218339454, 1.2332867368981812,
-                   3.290758645020128, -2.062057539750064, -0.2647664736747073, 1.4557156186351876, 1.3635213968518987,
-                   0, 0, 0, 0, 0, 0, 0, 0, 0.6, 0, 0, 1, 0, 0, 0]], dtype=np.float64)
-    g1, g2 = 9, 24
-    lim = o.CollisionAvoidanceLimit(model, [([g1], [g2])], collision_detection_distance=0.25,
-                                    minimum_distance_from_collisions=0.02)
-    assert lim.geom_id_pairs == [(g1, g2)]
-    d = o.Configuration(model, q[0]).data
-
-    def shape(g):
-        k = int(model.geom_dataid[g])
-        return dict(type=int(model.geom_type[g]), pos=np.asarray(d.geom_xpos[g], float),
-                    mat=np.asarray(d.geom_xmat[g], float).reshape(3, 3), size=np.asarray(model.geom_size[g], float),
-                    verts=model.mesh_vert[model.mesh_vertadr[k]:model.mesh_vertadr[k] + model.mesh_vertnum[k]])
-
-    A, Bm = shape(g1), shape(g2)
-    dist, pa, pb = cx.distance(A, Bm)
-    n = (pb - pa) / np.linalg.norm(pb - pa)
-    gap = cx.support(Bm, -n) @ n - cx.support(A, n) @ n
-    assert abs(dist - 0.13559789169) < 1e-10 and abs(gap - dist) < 1e-12
-    n_active, _, _ = compare_rows(model, lim, q)
-    assert n_active == 1
-
-
-def test_iteration_that_stops_improving_keeps_its_best_state():
-    """Second configuration found by the sweep: a cylinder (the post) against the hand's box, 1.89 cm
-    apart.  Next to the converged edge of the simplex a new support point adds only rounding, the
-    region tests of the needle triangle place the closest point in its interior (2.19 cm) and the
-    next step comes back to the edge: an iteration without the "no nearer, so stop" rule alternates
-    until its limit and answers with whichever state the limit fell on."""
-    from oracle import convex as cx
-    model = load_mjcf(os.path.join(HERE, "models", "convex_arm.xml"))
-    q = np.array([[0.09120999333720148, 0.042785596544025306, 0.6759032101083793, 0.8800319553123718, -0.3252792911446259,
-                   -0.22584473273315, -0.26216654454416033, 0.1675671275555356, 0.2639281790292487, -0.32887765798477103,
-                   0.2580108820272303, 0.07479242630156516, 0.011455947252039425, 0.25467128696568747, 0.6938206065779933,
-                   0.49744794258556063, -0.19642816824777673, -0.4822597692364161]])
-    g1, g2 = 1, 6
-    assert int(model.geom_type[g1]) == cx.CYLINDER and int(model.geom_type[g2]) == cx.BOX
+@pytest.mark.parametrize("case", ["FLAT_SIMPLEX", "TWO_STATE_CYCLE"])
+def test_configurations_that_break_an_unguarded_gjk(case):
+    """Found by the sweep of tools/soak_convex.py (tests/convex_cases.py says what goes wrong on each):
+    the kernels' row against the restatement's, whose distance carries its optimality certificate."""
+    import convex_cases as cc
+    c = getattr(cc, case)
+    model = cc.load_case_model(c)
+    g1, g2 = c["geoms"]
+    dist, gap = cc.distance_and_certificate(model, c["q"], g1, g2)
+    assert abs(dist - c["distance"]) < 1e-9 and abs(gap - dist) < 1e-9
     lim = o.CollisionAvoidanceLimit(model, [([g1], [g2])], collision_detection_distance=0.5,
                                     minimum_distance_from_collisions=0.01)
-    d = o.Configuration(model, q[0]).data
-    sh = [dict(type=int(model.geom_type[g]), pos=np.asarray(d.geom_xpos[g], float),
-               mat=np.asarray(d.geom_xmat[g], float).reshape(3, 3), size=np.asarray(model.geom_size[g], float))
-          for g in (g1, g2)]
-    dist, pa, pb = cx.distance(sh[0], sh[1])
-    n = (pb - pa) / np.linalg.norm(pb - pa)
-    gap = cx.support(sh[1], -n) @ n - cx.support(sh[0], n) @ n
-    assert abs(dist - 0.0189000266) < 1e-9 and abs(gap - dist) < 1e-9
-    n_active, _, _ = compare_rows(model, lim, q, atol=2e-5)
+    assert lim.geom_id_pairs == [(g1, g2)]
+    n_active, _, _ = compare_rows(model, lim, np.array([c["q"]], dtype=np.float64), atol=1e-8 if case == "FLAT_SIMPLEX" else 2e-5)
     assert n_active == 1
 
 
