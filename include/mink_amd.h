@@ -20,7 +20,8 @@
  *     MK_ERR_INVALID (one process per GPU never meets this); handles are immutable
  *     after creation and may be used from several threads / streams at once;
  *   - per-problem solver outcome goes to an int32 status array:
- *       0 solved, 1 iteration limit, 2 infeasible constraints, 3 non-finite input
+ *       0 solved, 1 iteration limit (or an answer of the general solver that fails its final check
+ *       of the active rows), 2 infeasible constraints, 3 non-finite input
  *     (a NaN / Inf anywhere in the problem's q row or targets: its velocity is zero and
  *     the iterated entries leave its q as it was; other problems are unaffected).
  *   - quaternions are (w, x, y, z); poses are (qw, qx, qy, qz, x, y, z) like

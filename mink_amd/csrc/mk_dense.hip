@@ -650,7 +650,7 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
   // only if the residuals it was computed from are smaller than those of the pass before (with
   // a Hessian singular to working precision the inverses are too poor to refine anything).
   if (status == 0) {
-    double x_prev = x, m_prev = INFINITY;
+    double x_prev = x, m_prev = INFINITY, s_kept = 0.0;
     double hmax = lane < n ? hrow[lane] : 0.0;   // largest diagonal entry of H: x units -> gradient units
     {
       int idm = lane;
@@ -690,9 +690,13 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
       // the size of this x's residuals decides whether the pass that produced it is kept
       double m = fmax(fabs(r), hmax * fabs(sres));
       if (!(m == m)) m = INFINITY;
+      double ms = fabs(sres);
+      if (!(ms == ms)) ms = INFINITY;
       {
         int idm = lane;
         wave_argmax(m, idm);
+        idm = lane;
+        wave_argmax(ms, idm);
       }
       if (!(m < m_prev)) {   // wave-uniform
         x = x_prev;
@@ -700,6 +704,7 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
       }
       x_prev = x;
       m_prev = m;
+      s_kept = ms;
       if (pass == 2) break;
       if (lane < n) s.hin[lane] = r;
       __syncthreads();
@@ -751,6 +756,20 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
     }
     if (act_hi && fabs(x - hi) <= 1e-9 * fmax(1.0, fabs(hi))) x = hi;
     if (act_lo && fabs(lo - x) <= 1e-9 * fmax(1.0, fabs(lo))) x = lo;
+    // The dual method only looks for violations among the rows it holds inactive; the active ones
+    // are met by construction -- up to what the explicit inverses lose.  An answer that misses its
+    // own active rows by more than 1e-7 of its size (cond(P) ~ 1e9 with many dense rows) is not
+    // handed out as solved.
+    // Likewise for stationarity: a residual of H x + c + N u above 1e-7 of the gradient's own scale.
+    {
+      double xm = lane < n ? fabs(x) : 0.0, cm = lane < n ? fabs(s.c[lane]) : 0.0;
+      int idm = lane;
+      wave_argmax(xm, idm);
+      idm = lane;
+      wave_argmax(cm, idm);
+      if (!(s_kept <= 1e-7 * fmax(1.0, xm))) status = 1;
+      if (!(m_prev <= 1e-7 * fmax(cm + hmax * xm, 1e-300))) status = 1;
+    }
   }
   x_out = x;
 #if defined(MK_DENSE_COUNT_STEPS)
