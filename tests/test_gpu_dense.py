@@ -284,3 +284,38 @@ def test_general_kernels_on_a_stiff_problem_match_the_fused_kernel():
           f"max {float(out.max()):.1f}; max |dv| {float((x / dt - v).abs().max()):.2e}")
     assert float(cond.median()) > 1e5
     assert float((x / dt - v).abs().max()) < 1e-8
+
+
+def test_dense_qp_answers_are_checked_before_they_are_handed_out():
+    """cond(P) = 1e9 with ten times more dense rows than unknowns: the explicit inverses of the dual
+    method fail on some of these problems.  Whatever comes back with status 0 must meet its rows and
+    be stationary; the rest must say so (status 1, or 2 where the iteration itself breaks down), not be
+    handed out as solved."""
+    from mink_amd.engine import qp_solve
+    rng = np.random.default_rng(808)
+    B, n, m, cond = 2048, 4, 40, 1e9
+    Q = np.linalg.qr(rng.normal(size=(B, n, n)))[0]
+    ev = np.exp(rng.uniform(0, np.log(cond), size=(B, n)))
+    ev[:, 0], ev[:, -1] = 1.0, cond
+    P = (Q * ev[:, None, :]) @ Q.transpose(0, 2, 1)
+    P = 0.5 * (P + P.transpose(0, 2, 1))
+    c = rng.normal(size=(B, n)) * 3 * np.sqrt(cond)
+    G = rng.normal(size=(B, m, n))
+    h = np.einsum("bij,bj->bi", G, rng.normal(size=(B, n)) * 0.1) + rng.uniform(0.01, 1.0, size=(B, m))
+    x, st = qp_solve(dev(P), dev(c), dev(G), dev(h))
+    x, st = x.cpu().numpy(), st.cpu().numpy()
+    assert set(np.unique(st).tolist()) <= {0, 1, 2}     # 2: the dual method's own breakdown (no step length left)
+    solved = st == 0
+    assert solved.mean() > 0.8
+    worst_feas = worst_stat = 0.0
+    for b in np.nonzero(solved)[0]:
+        r = G[b] @ x[b] - h[b]
+        worst_feas = max(worst_feas, float(r.max()))
+        g = P[b] @ x[b] + c[b]
+        act = r > -1e-6 * (1.0 + np.abs(h[b]))
+        lam = np.linalg.lstsq(G[b][act].T, -g, rcond=None)[0] if act.any() else np.zeros(0)
+        res = g + (G[b][act].T @ lam if act.any() else 0.0)
+        worst_stat = max(worst_stat, float(np.abs(res).max() / (np.abs(c[b]).max() + (np.abs(P[b]) @ np.abs(x[b])).max())))
+        assert lam.size == 0 or lam.min() > -1e-6 * np.abs(c[b]).max()
+    print(f"solved {int(solved.sum())} of {B}; worst bound violation {worst_feas:.1e}, worst relative stationarity {worst_stat:.1e}")
+    assert worst_feas < 1e-6 and worst_stat < 1e-9
