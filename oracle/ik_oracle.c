@@ -442,6 +442,68 @@ static void chol_solve(const double* L, int n, double* b) {
   }
 }
 
+/* The minimiser on the final active set, recomputed from the data: x = -H^-1 (c + N u) with
+ * (N' H^-1 N) u = -(b + N' H^-1 c), then one pass of iterative refinement on the KKT system with residuals
+ * from P, c, G, h themselves.  The dual iteration reaches the same point through a chain of updates of x and
+ * u whose rounding errors add up (1e-9 relative at cond(P) ~ 1e6); this restatement is the checker, so its
+ * answer should not be the less accurate one.  Leaves x alone if the active rows turn out dependent. */
+static void polish_qp(const double* P, const double* c, const double* G, const double* h, int n, const double* L,
+                      const int* act, int na, double* x) {
+  double HiN[MAXNV][MAXNV], M[MAXNV * MAXNV], LM[MAXNV * MAXNV], u[MAXNV], w[MAXNV], xn[MAXNV];
+  for (int a = 0; a < na; ++a) {
+    memcpy(HiN[a], G + (size_t)act[a] * n, n * sizeof(double));
+    chol_solve(L, n, HiN[a]);
+  }
+  for (int a = 0; a < na; ++a)
+    for (int b = 0; b <= a; ++b) {
+      const double* ga = G + (size_t)act[a] * n;
+      double s = 0.0;
+      for (int i = 0; i < n; ++i) s += ga[i] * HiN[b][i];
+      M[a * na + b] = M[b * na + a] = s;
+    }
+  if (na > 0 && chol(M, na, LM) != 0) return;
+  for (int i = 0; i < n; ++i) { xn[i] = 0.0; }
+  for (int a = 0; a < na; ++a) u[a] = 0.0;
+  for (int pass = 0; pass < 3; ++pass) {
+    /* residuals of the current (xn, u): r = P xn + c + N u, s = N' xn - b */
+    double r[MAXNV], sres[MAXNV], du[MAXNV];
+    for (int i = 0; i < n; ++i) {
+      double t = c[i];
+      for (int j = 0; j < n; ++j) t += P[i * n + j] * xn[j];
+      for (int a = 0; a < na; ++a) t += G[(size_t)act[a] * n + i] * u[a];
+      r[i] = t;
+    }
+    for (int a = 0; a < na; ++a) {
+      const double* ga = G + (size_t)act[a] * n;
+      double t = -h[act[a]];
+      for (int i = 0; i < n; ++i) t += ga[i] * xn[i];
+      sres[a] = t;
+    }
+    /* du = M^-1 (s - N' H^-1 r), dx = -H^-1 r - H^-1 N du */
+    memcpy(w, r, n * sizeof(double));
+    chol_solve(L, n, w);
+    for (int a = 0; a < na; ++a) {
+      const double* ga = G + (size_t)act[a] * n;
+      double t = sres[a];
+      for (int i = 0; i < n; ++i) t -= ga[i] * w[i];
+      du[a] = t;
+    }
+    if (na > 0) chol_solve(LM, na, du);
+    for (int i = 0; i < n; ++i) {
+      double t = w[i];
+      for (int a = 0; a < na; ++a) t += HiN[a][i] * du[a];
+      xn[i] -= t;
+    }
+    for (int a = 0; a < na; ++a) u[a] += du[a];
+  }
+  for (int i = 0; i < n; ++i)
+    if (!isfinite(xn[i])) return;
+  /* the polished point must still be the same vertex: multipliers not negative beyond rounding */
+  for (int a = 0; a < na; ++a)
+    if (u[a] < -1e-9 * (1.0 + fabs(u[a]))) return;
+  memcpy(x, xn, n * sizeof(double));
+}
+
 /* Goldfarb-Idnani dual active set. Returns 0 ok, 1 iteration limit, 2 infeasible. */
 static int solve_qp(const double* P, const double* c, const double* G, const double* h, int n, int m, double* x) {
   double L[MAXNV * MAXNV];
@@ -470,7 +532,10 @@ static int solve_qp(const double* P, const double* c, const double* G, const dou
       s /= rn[j];
       if (s > worst) { worst = s; p = j; }
     }
-    if (p < 0) return 0;
+    if (p < 0) {
+      polish_qp(P, c, G, h, n, L, act, na, x);
+      return 0;
+    }
     const double* np = G + (size_t)p * n;
     double up = 0.0;
     for (;;) {
