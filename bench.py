@@ -113,6 +113,8 @@ def cpu_baseline(model, q0_np, targets_np, gpu_q_final):
     cores = min(16, len(os.sched_getaffinity(0)))
     orc = co.COracle(model, postures=[dict(cost=W.posture_cost(model), target_q=W.home_q(model))],
                      velocity=W.VELOCITY_LIMITS)
+    # timed as the algorithm the reference runs: the dual iteration without the checker's polish step
+    co.lib().or_set_polish(0)
 
     def run(n, threads):
         t = time.perf_counter()

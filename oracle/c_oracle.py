@@ -52,6 +52,8 @@ def lib():
         _lib.or_solve_qp.restype = C.c_int
         _lib.or_solve_ik_batch.restype = None
         _lib.or_iterate_batch.restype = None
+        _lib.or_set_polish.restype = None
+        _lib.or_set_polish.argtypes = [C.c_int]
     return _lib
 
 

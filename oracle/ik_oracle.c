@@ -447,6 +447,8 @@ static void chol_solve(const double* L, int n, double* b) {
  * from P, c, G, h themselves.  The dual iteration reaches the same point through a chain of updates of x and
  * u whose rounding errors add up (1e-9 relative at cond(P) ~ 1e6); this restatement is the checker, so its
  * answer should not be the less accurate one.  Leaves x alone if the active rows turn out dependent. */
+static int g_polish = 1; /* or_set_polish(0): the plain dual iteration, as timed for the CPU baseline */
+
 static void polish_qp(const double* P, const double* c, const double* G, const double* h, int n, const double* L,
                       const int* act, int na, double* x) {
   double HiN[MAXNV][MAXNV], M[MAXNV * MAXNV], LM[MAXNV * MAXNV], u[MAXNV], w[MAXNV], xn[MAXNV];
@@ -533,7 +535,7 @@ static int solve_qp(const double* P, const double* c, const double* G, const dou
       if (s > worst) { worst = s; p = j; }
     }
     if (p < 0) {
-      polish_qp(P, c, G, h, n, L, act, na, x);
+      if (g_polish) polish_qp(P, c, G, h, n, L, act, na, x);
       return 0;
     }
     const double* np = G + (size_t)p * n;
@@ -630,6 +632,9 @@ int or_build_qp(const or_model* m, const or_problem* p, const double* q, const d
                 double damping, double* P, double* c, double* G, double* h, double* e6) {
   return build_qp(m, p, q, target, dt, damping, P, c, G, h, e6);
 }
+
+/* 1 (default): answers are polished on their final active set (checker); 0: the dual iteration alone. */
+void or_set_polish(int on) { g_polish = on; }
 
 int or_solve_qp(const double* P, const double* c, const double* G, const double* h, int n, int m, double* x) {
   return solve_qp(P, c, G, h, n, m, x);
