@@ -294,13 +294,11 @@ def other_workloads(model, dm, prob, q0, targets, out, device, barrier):
               err=torch.empty((Bl, 6), dtype=torch.float64, device=device),
               status=torch.empty(Bl, dtype=torch.int32, device=device))
     big = {}
-    for name, knob in (("streaming", None), ("block_per_64", "0")):
-        if knob is not None:
-            os.environ["MK_FUSED_STREAM_BLOCKS"] = knob
+    for name, knob in (("streaming", -1), ("block_per_64", 0)):
         for b in ql:
             b.copy_(ql0)
-        wl, el = time_launches(lambda i: pn.iterate_(ql[i], tl, W.DT, W.DAMPING, 20, 1e-4, 1e-4, out=ol), 3, 1, barrier)
-        os.environ.pop("MK_FUSED_STREAM_BLOCKS", None)
+        with L.options(stream_blocks=knob):
+            wl, el = time_launches(lambda i: pn.iterate_(ql[i], tl, W.DT, W.DAMPING, 20, 1e-4, 1e-4, out=ol), 3, 1, barrier)
         st = loop_stats(ol)
         big[name] = dict(ms_per_launch=1e3 * el / 3, solves_per_s=Bl * st["mean_solves"] * 3 / wl,
                          problems_per_s=Bl * 3 / wl)
@@ -344,12 +342,9 @@ def other_workloads(model, dm, prob, q0, targets, out, device, barrier):
     wl, el = time_launches(lambda i: p4.iterate_(ql[i], tl, W.DT, W.DAMPING, 20, -1.0, -1.0, out=out4), 2, 1, barrier)
     loop4 = {"staged_passes": {"solves_per_s": Bl * 20 * 2 / wl, "ms_per_loop": 1e3 * el / 2},
              "status_nonzero": int((out4["status"] != 0).sum().item())}
-    os.environ["MK_NO_STAGED_LOOP"] = "1"
-    try:
+    with L.options(staged_loop=0):
         qg = [q4[:Bl].clone() for _ in range(2)]
         wg, eg = time_launches(lambda i: p4.iterate_(qg[i], tl, W.DT, W.DAMPING, 20, -1.0, -1.0, out=out4), 1, 1, barrier)
-    finally:
-        del os.environ["MK_NO_STAGED_LOOP"]
     loop4["general_kernel_passes"] = {"solves_per_s": Bl * 20 / wg, "ms_per_loop": 1e3 * eg}
     loop4["max_abs_q_diff"] = float((ql[2] - qg[1]).abs().max().item())
     extra["config4_loop_B65536_x20"] = loop4

@@ -298,6 +298,26 @@ int mk_lie_batch(int32_t op, const double* d_a, const double* d_b, int32_t B, do
 /* Operand widths of an operation; returns MK_ERR_INVALID for an unknown op. */
 int mk_lie_op_shape(int32_t op, int32_t* wa, int32_t* wb, int32_t* wo);
 
+/* Process-wide switches.  No counterpart in the reference (its solver backend is picked by the
+ * `solver` string of mink.solve_ik, mink/solve_ik.py:68-77, and has no tuning surface); these
+ * choose between equivalent kernel paths and serve the tests and tuning tools.  Every path
+ * returns the same results to the stated tolerances, so a caller never needs them.
+ *   "coop"            -1 (default): problems of the fused path with B <= "coop_max_batch" run on the
+ *                     cooperative kernels (16 lanes per problem: small batches, the 200 Hz loop of
+ *                     interactive_scripts/teleop_mouse.py:99-125); 0 never; 1 always
+ *   "coop_max_batch"  default 16384
+ *   "coop_refine"     1: the cooperative solver adds one step of iterative refinement per solve
+ *   "stream_blocks"   -1 (default): lane streaming of the iterated entry by batch size; 0 never;
+ *                     n > 0 always, with n persistent waves
+ *   "stream_refill"   default 16: waiting lanes before the streaming kernels hand out problems
+ *   "staged"          0: problems with collision limits skip the staged solve (read by mk_problem_create)
+ *   "lane_rows", "general_stage", "staged_loop"   0: skip that stage of the staged solve
+ *                     (diagnostic; without "general_stage" the problems it would have solved
+ *                     report status 1)
+ * Unknown names give MK_ERR_INVALID.  Values are read at launch time with relaxed atomics. */
+int mk_set_option(const char* name, int64_t value);
+int mk_get_option(const char* name, int64_t* value);
+
 /* Message of the last error on the calling thread ("" if none). */
 const char* mk_last_error(void);
 

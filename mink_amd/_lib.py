@@ -186,6 +186,8 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "mk_lie_batch": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mk_lie_op_shape": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mk_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+    "mk_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -234,3 +236,34 @@ def check(code: int) -> None:
     if code != MK_OK:
         msg = load_library().mk_last_error()
         raise MinkAmdError(code, msg.decode() if msg else "")
+
+
+def set_option(name: str, value: int) -> None:
+    """mk_set_option: a process-wide switch between equivalent kernel paths (include/mink_amd.h)."""
+    check(load_library().mk_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    out = C.c_int64(0)
+    check(load_library().mk_get_option(name.encode(), C.byref(out)))
+    return int(out.value)
+
+
+class options:
+    """Context manager: ``with options(coop=1, stream_blocks=0): ...`` sets the switches and
+    restores their previous values on exit (tests and tuning tools)."""
+
+    def __init__(self, **values: int):
+        self._values = values
+        self._saved: dict = {}
+
+    def __enter__(self):
+        for k, v in self._values.items():
+            self._saved[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self._saved.items():
+            set_option(k, v)
+        return False

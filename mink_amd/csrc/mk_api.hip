@@ -16,6 +16,40 @@
 #include "../../include/mink_amd.h"
 #include "mk_device.h"
 #include "mk_generic.h"
+#include "mk_options.h"
+
+#include <atomic>
+
+// ---- process-wide switches (mk_options.h) ----
+namespace {
+struct MkOptionEntry {
+  const char* name;
+  long initial;
+};
+const MkOptionEntry kOptions[MK_OPT_COUNT] = {
+    {"staged", 1},        {"lane_rows", 1},     {"general_stage", 1}, {"staged_loop", 1},        {"stream_blocks", -1},
+    {"stream_refill", 16}, {"coop", -1},        {"coop_max_batch", 16384}, {"coop_refine", 0},
+};
+std::atomic<long>* option_table() {
+  static std::atomic<long> table[MK_OPT_COUNT];
+  static const bool init = [] {
+    for (int i = 0; i < MK_OPT_COUNT; ++i) table[i].store(kOptions[i].initial, std::memory_order_relaxed);
+    return true;
+  }();
+  (void)init;
+  return table;
+}
+}  // namespace
+long mk_opt(MkOption o) { return option_table()[o].load(std::memory_order_relaxed); }
+
+// ---- launchers implemented in mk_coop.hip ----
+hipError_t mk_coop_launch_step(int nc, bool refine, const MkFusedDesc* d_desc, const double* q, const double* targets,
+                               int target_stride, double dt, double damping, int B, double* v, int32_t* status,
+                               hipStream_t stream);
+hipError_t mk_coop_launch_iterate(int nc, bool refine, const MkFusedDesc* d_desc, double* q, const double* targets,
+                                  int target_stride, double dt, double damping, int B, int max_iters, double pos_tol,
+                                  double ori_tol, double* v, int32_t* iters, double* err, int32_t* status,
+                                  hipStream_t stream);
 
 // ---- launchers implemented in mk_fused.hip ----
 hipError_t mk_fused_launch_step(int nc, const MkFusedDesc* d_desc, int nq, const double* q, const double* targets,
@@ -1028,8 +1062,8 @@ int mk_problem_create(const mk_model* model, const mk_task_desc* tasks, int32_t 
     std::string why2;
     bool needs = false;
     int nck = 0;
-    // (MK_NO_STAGED set: tests and timing of the general kernel alone)
-    if (!getenv("MK_NO_STAGED") &&
+    // (option "staged" = 0: tests and timing of the general kernel alone)
+    if (mk_opt(MK_OPT_STAGED) != 0 &&
         build_fused(m, tasks, ntask, limits, nlimit, p->h_fused, &nck, why2, &p->h_ext, &needs) && needs) {
       p->staged = true;
       p->nc_kernel = nck;
@@ -1128,6 +1162,37 @@ int mk_problem_set_posture_target(mk_problem* p, int32_t task, const double* tar
   return MK_OK;
 }
 
+// Which form of the fused kernels serves a batch of B problems: the lane-per-problem kernels
+// need 64 problems per wave to be worth their long sequential solves; below about one problem
+// per four lanes of the machine the cooperative kernels (16 lanes per problem) finish sooner.
+// Posture tasks with a Levenberg-Marquardt term stay with the lane form.
+static bool use_coop(const mk_problem* p, int B) {
+  if (!p->fused || p->h_fused.any_posture_lm) return false;
+  const long mode = mk_opt(MK_OPT_COOP);
+  if (mode == 0) return false;
+  return mode > 0 || B <= mk_opt(MK_OPT_COOP_MAX_BATCH);
+}
+
+int mk_set_option(const char* name, int64_t value) {
+  if (!name) return fail(MK_ERR_INVALID, "null option name");
+  for (int i = 0; i < MK_OPT_COUNT; ++i)
+    if (strcmp(name, kOptions[i].name) == 0) {
+      option_table()[i].store((long)value, std::memory_order_relaxed);
+      return MK_OK;
+    }
+  return fail(MK_ERR_INVALID, "unknown option '%s'", name);
+}
+
+int mk_get_option(const char* name, int64_t* value) {
+  if (!name || !value) return fail(MK_ERR_INVALID, "null argument");
+  for (int i = 0; i < MK_OPT_COUNT; ++i)
+    if (strcmp(name, kOptions[i].name) == 0) {
+      *value = option_table()[i].load(std::memory_order_relaxed);
+      return MK_OK;
+    }
+  return fail(MK_ERR_INVALID, "unknown option '%s'", name);
+}
+
 int mk_solve_ik_batch(const mk_problem* p, const double* d_q, const double* d_targets, double dt, double damping,
                       int32_t B, double* d_v, int32_t* d_status, void* stream) {
   if (!p) return fail(MK_ERR_INVALID, "null problem");
@@ -1145,21 +1210,30 @@ int mk_solve_ik_batch(const mk_problem* p, const double* d_q, const double* d_ta
     MK_HIP(mk_fused_launch_step_ext(p->nc_kernel, p->d_fused, p->d_ext, p->info.nq, d_q, d_targets, p->info.target_stride,
                                     dt, damping, B, d_v, d_status, static_cast<hipStream_t>(stream),
                                     3 * p->h_ext.ncgeom + 4 * p->h_ext.norient));
-    const bool lane_rows = getenv("MK_NO_LANE_ROWS") == nullptr;   // tuning / tests: skip the middle stage
+    const bool lane_rows = mk_opt(MK_OPT_LANE_ROWS) != 0;   // tuning / tests: skip the middle stage
     if (p->h_ext.ncpair > 0 && lane_rows)
       MK_HIP(mk_fused_launch_rows(p->nc_kernel, p->d_fused, p->d_ext, p->info.nv, d_q, d_targets, p->info.target_stride,
                                   dt, damping, B, d_v, d_status, static_cast<hipStream_t>(stream)));
-    const bool general_stage = getenv("MK_NO_GENERAL_STAGE") == nullptr;   // tuning / tests: leave the rest pending
+    // diagnostic switch of the tests: without the last stage, the problems it would have solved
+    // come back with status 1 (the pending bit never reaches the caller)
+    const bool general_stage = mk_opt(MK_OPT_GENERAL_STAGE) != 0;
     if (p->h_ext.ncpair > 0 && general_stage)
       MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets,
                              p->info.target_stride, dt, damping, B, nullptr, nullptr, nullptr, nullptr, d_v, d_status, -1,
                              nullptr, nullptr, static_cast<hipStream_t>(stream), nullptr, false, true));
+    else if (p->h_ext.ncpair > 0)
+      MK_HIP(mk_generic_resolve_pending(d_status, B, static_cast<hipStream_t>(stream)));
     return MK_OK;
   }
   if (!p->fused) {
     MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets, p->info.target_stride, dt,
                            damping, B, nullptr, nullptr, nullptr, nullptr, d_v, d_status, -1, nullptr, nullptr,
                            static_cast<hipStream_t>(stream)));
+    return MK_OK;
+  }
+  if (use_coop(p, B)) {
+    MK_HIP(mk_coop_launch_step(p->nc_kernel, mk_opt(MK_OPT_COOP_REFINE) != 0, p->d_fused, d_q, d_targets,
+                               p->info.target_stride, dt, damping, B, d_v, d_status, static_cast<hipStream_t>(stream)));
     return MK_OK;
   }
   MK_HIP(mk_fused_launch_step(p->nc_kernel, p->d_fused, p->info.nq, d_q, d_targets, p->info.target_stride, dt,
@@ -1176,7 +1250,7 @@ int mk_solve_ik_iterate_batch(const mk_problem* p, double* d_q, const double* d_
   MK_ON_DEVICE(p->model);
   if (!d_q || !d_status) return fail(MK_ERR_INVALID, "null argument");
   if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
-  if (p->staged && !getenv("MK_NO_STAGED_LOOP")) {
+  if (p->staged && mk_opt(MK_OPT_STAGED_LOOP) != 0) {
     // Staged problems: one pass of the loop = the structured kernel in its loop mode (error, exit
     // test and bookkeeping of the pass, then the solve of the problems still in the loop), the
     // rows stage and the general kernel for what is pending, and the integration.  The optional
@@ -1238,6 +1312,12 @@ int mk_solve_ik_iterate_batch(const mk_problem* p, double* d_q, const double* d_
       MK_HIP(mk_generic_integrate(p->model->dev, d_q, d_v, dt, B, st, d_iters));
     }
     MK_HIP(mk_generic_iterate_finish(d_iters, B, st));
+    return MK_OK;
+  }
+  if (use_coop(p, B)) {
+    MK_HIP(mk_coop_launch_iterate(p->nc_kernel, mk_opt(MK_OPT_COOP_REFINE) != 0, p->d_fused, d_q, d_targets,
+                                  p->info.target_stride, dt, damping, B, max_iters, pos_tol, ori_tol, d_v, d_iters, d_err,
+                                  d_status, static_cast<hipStream_t>(stream)));
     return MK_OK;
   }
   MK_HIP(mk_fused_launch_iterate(p->nc_kernel, p->d_fused, p->info.nq, d_q, d_targets, p->info.target_stride, dt,

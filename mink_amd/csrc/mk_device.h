@@ -445,3 +445,26 @@ MK_DEV void se3_ljacinv_blocks(Twist xi, M3& Ji, M3& B) {
 #pragma unroll
   for (int i = 0; i < 9; ++i) B.m[i] = -B.m[i];
 }
+
+// Frame-task error e = log(T_wb^-1 T_wt) (mink/tasks/frame_task.py:95-122) of the frame at
+// (Q, t, R = mat(Q)) for the target (Qt, pt).
+MK_DEV Twist frame_error(Q4 Q, V3 t, const M3& R, Q4 Qt, V3 pt) { return se3_log(qmul(qconj(Q), Qt), mulT(R, pt - t)); }
+
+// LinearWaypointReach.step (envs/robot_utils.py:131-160) for the current pose (Qc, tc) and
+// the goal (Qg, pg): the commanded pose (Qt, pt) -- a step of at most pos_step along the
+// straight line to the goal position (the goal itself once within pos_thr), half-way along
+// the geodesic to the goal orientation -- and whether the goal counts as reached (position
+// within pos_thr and the norm of the x-y-z Euler angles of goal * current^-1 below rot_thr).
+MK_DEV bool waypoint_step(Q4 Qc, V3 tc, Q4 Qg, V3 pg, double pos_thr, double pos_step, double rot_thr, Q4& Qt,
+                          V3& pt) {
+  const V3 delta = pg - tc;
+  const double dist = sqrt(dot(delta, delta));
+  const bool pos_reached = dist < pos_thr;
+  const double step = fmin(dist, pos_step);
+  const V3 moved = tc + (step / fmax(dist, 1e-300)) * delta;
+  pt = pos_reached ? pg : moved;
+  const V3 half = 0.5 * so3_log(qmul(qconj(Qc), Qg));
+  Qt = qmul(Qc, so3_exp(half));
+  const V3 eul = quat_rpy(qmul(Qg, qconj(Qc)));
+  return pos_reached && sqrt(dot(eul, eul)) < rot_thr;
+}

@@ -19,6 +19,7 @@
 #include "mk_device.h"
 #include "mk_generic.h"
 #include "mk_geom.h"
+#include "mk_options.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -359,10 +360,6 @@ MK_DEV void chain_jac_pose(const MkFusedDesc* __restrict__ D, const double (&qc)
     *tcap = t;
   }
 }
-
-// Frame-task error e = log(T_wb^-1 T_wt) (mink/tasks/frame_task.py:95-122) of the frame at
-// (Q, t, R = mat(Q)) for the target (Qt, pt).
-MK_DEV Twist frame_error(Q4 Q, V3 t, const M3& R, Q4 Qt, V3 pt) { return se3_log(qmul(qconj(Q), Qt), mulT(R, pt - t)); }
 
 template <int NC>
 MK_DEV void chain_jac(const MkFusedDesc* __restrict__ D, const double (&qc)[NC], Q4 Qt, V3 pt, ChainJac<NC>& cj) {
@@ -1713,25 +1710,6 @@ __global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __
   }
 }
 
-// LinearWaypointReach.step (envs/robot_utils.py:131-160) for the current pose (Qc, tc) and
-// the goal (Qg, pg): the commanded pose (Qt, pt) -- a step of at most pos_step along the
-// straight line to the goal position (the goal itself once within pos_thr), half-way along
-// the geodesic to the goal orientation -- and whether the goal counts as reached (position
-// within pos_thr and the norm of the x-y-z Euler angles of goal * current^-1 below rot_thr).
-MK_DEV bool waypoint_step(Q4 Qc, V3 tc, Q4 Qg, V3 pg, double pos_thr, double pos_step, double rot_thr, Q4& Qt,
-                          V3& pt) {
-  const V3 delta = pg - tc;
-  const double dist = sqrt(dot(delta, delta));
-  const bool pos_reached = dist < pos_thr;
-  const double step = fmin(dist, pos_step);
-  const V3 moved = tc + (step / fmax(dist, 1e-300)) * delta;
-  pt = pos_reached ? pg : moved;
-  const V3 half = 0.5 * so3_log(qmul(qconj(Qc), Qg));
-  Qt = qmul(Qc, so3_exp(half));
-  const V3 eul = quat_rpy(qmul(Qg, qconj(Qc)));
-  return pos_reached && sqrt(dot(eul, eul)) < rot_thr;
-}
-
 // Waypoint reaching (envs/mj_env.py:193-276 with envs/robot_utils.py:113-160) as one launch.
 // Per problem the reference runs, for up to max_steps outer steps: the pose of the task
 // frame; the waypoint generator (bounded linear step towards the goal position, half-way
@@ -1919,8 +1897,7 @@ static hipError_t launch_iterate_stream(const MkFusedDesc* d_desc, int nq, doubl
                                         double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
                                         int32_t* status, hipStream_t stream) {
   const int chunk = (B + blocks - 1) / blocks;
-  int refill_min = 16;
-  if (const char* ev = getenv("MK_FUSED_STREAM_REFILL")) refill_min = atoi(ev);   // tuning
+  const int refill_min = (int)mk_opt(MK_OPT_STREAM_REFILL);   // tuning
   const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
   if (hipError_t e = allow_lds<fused_iterate_stream_kernel<NC>>(lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(fused_iterate_stream_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
@@ -2008,12 +1985,11 @@ hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, do
   // problems per wave with coalesced tile copies.
   int slots = wave_slots();
   bool stream_path = (long)B >= 2L * 64 * slots;
-  // MK_FUSED_STREAM_BLOCKS=<n> (tests, tuning): take the streaming kernel with n persistent
+  // option "stream_blocks" = n (tests, tuning): take the streaming kernel with n persistent
   // waves whatever the batch size; 0 switches it off
-  if (const char* ev = getenv("MK_FUSED_STREAM_BLOCKS")) {
-    const int n = atoi(ev);
+  if (const long n = mk_opt(MK_OPT_STREAM_BLOCKS); n >= 0) {
     stream_path = n > 0;
-    if (n > 0) slots = n;
+    if (n > 0) slots = (int)n;
   }
   if (stream_path && (pos_tol >= 0.0 && ori_tol >= 0.0) && max_iters > 1) {
     switch (nc) {
@@ -2045,12 +2021,10 @@ static hipError_t launch_move_to(const MkFusedDesc* d_desc, int nq, double* q, c
   // one persistent wave per wave slot of the device at most; with fewer problems than lanes
   // every lane gets exactly one problem
   int slots = wave_slots();
-  if (const char* ev = getenv("MK_FUSED_STREAM_BLOCKS"))
-    if (atoi(ev) > 0) slots = atoi(ev);
+  if (const long n = mk_opt(MK_OPT_STREAM_BLOCKS); n > 0) slots = (int)n;
   const int blocks = std::max(1, std::min((B + 63) / 64, slots));
   const int chunk = (B + blocks - 1) / blocks;
-  int refill_min = 16;
-  if (const char* ev = getenv("MK_FUSED_STREAM_REFILL")) refill_min = atoi(ev);   // tuning
+  const int refill_min = (int)mk_opt(MK_OPT_STREAM_REFILL);   // tuning
   const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
   if (hipError_t e = allow_lds<fused_move_to_kernel<NC>>(lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(fused_move_to_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, goals, dt, damping, B,

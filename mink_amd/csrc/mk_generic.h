@@ -6,26 +6,29 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
 
 // Dynamic LDS beyond the 64 KB default needs the kernel's limit raised.  The largest size
 // already granted is remembered per kernel and device, so this is one runtime call per kernel
-// and device (or per new high-water mark), not one per launch.
+// and device (or per new high-water mark), not one per launch.  Raising the limit is serialised:
+// two threads asking for different sizes must not leave the attribute at the smaller one.
 struct MkLdsGrant {
   std::atomic<size_t> granted[32];
+  std::mutex raise;
 };
 inline hipError_t mk_grant_lds(const void* kernel, size_t lds, MkLdsGrant& g) {
   if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (lds <= 64 * 1024) return hipSuccess;
   int dev = -1;
   if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
   const bool tracked = dev >= 0 && dev < 32;
+  if (tracked && lds <= g.granted[dev].load(std::memory_order_acquire)) return hipSuccess;
+  std::lock_guard<std::mutex> lock(g.raise);
   const size_t have = tracked ? g.granted[dev].load(std::memory_order_relaxed) : 0;
-  if (lds <= (have > 64 * 1024 ? have : 64 * 1024)) return hipSuccess;
+  if (lds <= have) return hipSuccess;
   if (hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
     return e;
-  if (tracked) {
-    size_t cur = have;
-    while (cur < lds && !g.granted[dev].compare_exchange_weak(cur, lds, std::memory_order_relaxed)) {}
-  }
+  if (tracked) g.granted[dev].store(lds, std::memory_order_release);
   return hipSuccess;
 }
 
@@ -118,6 +121,8 @@ hipError_t mk_generic_integrate(const MkDevModel& m, double* q, const double* v,
 // any other live problem is about to be solved and its count becomes it + 1.
 hipError_t mk_generic_iterate_mark(int32_t* iters, const double* err, int B, int it, int max_iters, double pos_tol,
                                    double ori_tol, bool has_frame, hipStream_t s);
+// Status entries that still carry MK_STATUS_PENDING (mk_device.h) become status 1.
+hipError_t mk_generic_resolve_pending(int32_t* status, int B, hipStream_t s);
 // Clears the done bits: `iters` then holds the solves executed.
 hipError_t mk_generic_iterate_finish(int32_t* iters, int B, hipStream_t s);
 // Pose (d_pose != null) and/or body-frame Jacobian (d_jac != null) of a frame given

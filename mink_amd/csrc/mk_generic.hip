@@ -124,7 +124,18 @@ __global__ void iterate_finish_kernel(int32_t* __restrict__ iters, int B) {
   if (b < B) iters[b] &= ~MK_ITER_DONE_BIT;
 }
 
+// A status entry that still carries the pending bit becomes status 1 (not solved).
+__global__ void resolve_pending_kernel(int32_t* __restrict__ status, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B && (status[b] & MK_STATUS_PENDING) != 0) status[b] = 1;
+}
+
 }  // namespace
+
+hipError_t mk_generic_resolve_pending(int32_t* status, int B, hipStream_t s) {
+  hipLaunchKernelGGL(resolve_pending_kernel, dim3((B + 255) / 256), dim3(256), 0, s, status, B);
+  return hipGetLastError();
+}
 
 hipError_t mk_generic_integrate(const MkDevModel& m, double* q, const double* v, double dt, int B, hipStream_t s,
                                 const int32_t* skip_flags) {

@@ -6,8 +6,11 @@
 // logic can be checked against the oracle in the CPU test suite (no GPU needed).
 // It is never loaded by the mink_amd package.
 #define MK_QP_STATS 1
+#define MK_COOP_HOSTSIM 1
+#include "coop_sim.h"
 #include "../../mink_amd/csrc/mk_api.hip"
 #include "../../mink_amd/csrc/mk_fused.hip"
+#include "../../mink_amd/csrc/mk_coop.hip"
 
 namespace {
 
@@ -251,4 +254,54 @@ extern "C" void hostsim_qp_stats(long* out, int reset) {
 #if !defined(__HIP_DEVICE_COMPILE__)
   for (int i = 0; i < 4; ++i) { out[i] = g_qp_stats[i]; if (reset) g_qp_stats[i] = 0; }
 #endif
+}
+
+// ---- the cooperative (16 lanes per problem) form, one row of fibers per problem ----
+template <int NC>
+int run_coop_step(const MkFusedDesc& D, const double* q, const double* targets, int stride, double dt, double damping,
+                  int B, double* v, int32_t* status, int refine) {
+  for (long g = 0; g < B; ++g)
+    cosim::run_row([&] {
+      if (refine) coop_step_body<NC, true>(&D, q, targets, stride, dt, damping, B, v, status, g);
+      else coop_step_body<NC, false>(&D, q, targets, stride, dt, damping, B, v, status, g);
+    });
+  return 0;
+}
+
+template <int NC>
+int run_coop_iterate(const MkFusedDesc& D, double* q, const double* targets, int stride, double dt, double damping, int B,
+                     int max_iters, double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
+                     int32_t* status, int refine) {
+  for (long g = 0; g < B; ++g)
+    cosim::run_row([&] {
+      if (refine)
+        coop_iterate_body<NC, true>(&D, q, targets, stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err,
+                                    status, g);
+      else
+        coop_iterate_body<NC, false>(&D, q, targets, stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err,
+                                     status, g);
+    });
+  return 0;
+}
+
+extern "C" int hostsim_coop_solve_ik(const mk_model_desc* md, const mk_task_desc* tasks, int ntask,
+                                     const mk_limit_desc* limits, int nlimit, const double* q, const double* targets,
+                                     double dt, double damping, int B, double* v, int32_t* status, int refine) {
+  static MkFusedDesc D;
+  int nk, stride;
+  int rc = build(md, tasks, ntask, limits, nlimit, D, &nk, &stride);
+  if (rc != MK_OK) return rc;
+  HS_DISPATCH(run_coop_step, D, q, targets, stride, dt, damping, B, v, status, refine)
+}
+
+extern "C" int hostsim_coop_iterate(const mk_model_desc* md, const mk_task_desc* tasks, int ntask,
+                                    const mk_limit_desc* limits, int nlimit, double* q, const double* targets, double dt,
+                                    double damping, int B, int max_iters, double pos_tol, double ori_tol, double* v,
+                                    int32_t* iters, double* err, int32_t* status, int refine) {
+  static MkFusedDesc D;
+  int nk, stride;
+  int rc = build(md, tasks, ntask, limits, nlimit, D, &nk, &stride);
+  if (rc != MK_OK) return rc;
+  HS_DISPATCH(run_coop_iterate, D, q, targets, stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status,
+              refine)
 }

@@ -24,6 +24,8 @@ def _load():
         _h = C.CDLL(PATH)
         _h.hostsim_solve_ik.restype = C.c_int
         _h.hostsim_iterate.restype = C.c_int
+        _h.hostsim_coop_solve_ik.restype = C.c_int
+        _h.hostsim_coop_iterate.restype = C.c_int
         _h.mk_last_error.restype = C.c_char_p
     return _h
 
@@ -32,7 +34,9 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def solve_ik(model, task_specs, limit_specs, q, targets, dt, damping):
+def solve_ik(model, task_specs, limit_specs, q, targets, dt, damping, form="lane", refine=0):
+    """form = "lane": the lane-per-problem device functions of mk_fused.hip; "coop": the
+    cooperative ones of mk_coop.hip, their 16 lanes emulated by fibers."""
     h = _load()
     md, k1 = L.pack_model(model)
     ta, k2 = L.pack_tasks(task_specs)
@@ -42,14 +46,20 @@ def solve_ik(model, task_specs, limit_specs, q, targets, dt, damping):
     B = q.shape[0]
     v = np.zeros((B, model.nv))
     status = np.zeros(B, dtype=np.int32)
-    rc = h.hostsim_solve_ik(C.byref(md), ta, C.c_int(len(task_specs)), la, C.c_int(len(limit_specs)), _ptr(q),
-                            _ptr(targets), C.c_double(dt), C.c_double(damping), C.c_int(B), _ptr(v), _ptr(status))
+    if form == "coop":
+        rc = h.hostsim_coop_solve_ik(C.byref(md), ta, C.c_int(len(task_specs)), la, C.c_int(len(limit_specs)), _ptr(q),
+                                     _ptr(targets), C.c_double(dt), C.c_double(damping), C.c_int(B), _ptr(v),
+                                     _ptr(status), C.c_int(refine))
+    else:
+        rc = h.hostsim_solve_ik(C.byref(md), ta, C.c_int(len(task_specs)), la, C.c_int(len(limit_specs)), _ptr(q),
+                                _ptr(targets), C.c_double(dt), C.c_double(damping), C.c_int(B), _ptr(v), _ptr(status))
     if rc != 0:
         raise RuntimeError(f"hostsim rc={rc}: {h.mk_last_error().decode()}")
     return v, status
 
 
-def iterate(model, task_specs, limit_specs, q, targets, dt, damping, max_iters, pos_tol, ori_tol):
+def iterate(model, task_specs, limit_specs, q, targets, dt, damping, max_iters, pos_tol, ori_tol, form="lane",
+            refine=0):
     h = _load()
     md, k1 = L.pack_model(model)
     ta, k2 = L.pack_tasks(task_specs)
@@ -61,9 +71,10 @@ def iterate(model, task_specs, limit_specs, q, targets, dt, damping, max_iters, 
     iters = np.zeros(B, dtype=np.int32)
     err = np.zeros((B, 6))
     status = np.zeros(B, dtype=np.int32)
-    rc = h.hostsim_iterate(C.byref(md), ta, C.c_int(len(task_specs)), la, C.c_int(len(limit_specs)), _ptr(q),
-                           _ptr(targets), C.c_double(dt), C.c_double(damping), C.c_int(B), C.c_int(max_iters),
-                           C.c_double(pos_tol), C.c_double(ori_tol), _ptr(v), _ptr(iters), _ptr(err), _ptr(status))
+    args = (C.byref(md), ta, C.c_int(len(task_specs)), la, C.c_int(len(limit_specs)), _ptr(q),
+            _ptr(targets), C.c_double(dt), C.c_double(damping), C.c_int(B), C.c_int(max_iters),
+            C.c_double(pos_tol), C.c_double(ori_tol), _ptr(v), _ptr(iters), _ptr(err), _ptr(status))
+    rc = h.hostsim_coop_iterate(*args, C.c_int(refine)) if form == "coop" else h.hostsim_iterate(*args)
     if rc != 0:
         raise RuntimeError(f"hostsim rc={rc}: {h.mk_last_error().decode()}")
     return q, v, iters, err, status

@@ -196,11 +196,8 @@ def test_staged_solve_matches_general_kernel(env):
     q, tg = W.config4_inputs(model, dm, B, 5)
     staged = DeviceProblem(dm, tasks, limits)
     assert staged.staged and not staged.fused and staged.n_chain == 10
-    os.environ["MK_NO_STAGED"] = "1"
-    try:
+    with L.options(staged=0):
         general = DeviceProblem(dm, tasks, limits)
-    finally:
-        del os.environ["MK_NO_STAGED"]
     assert not general.staged
     v_s, st_s = staged.solve(q, tg, W.DT, W.DAMPING)
     v_g, st_g = general.solve(q, tg, W.DT, W.DAMPING)
@@ -239,11 +236,8 @@ def test_staged_relative_frame_without_collision(env):
         tasks = [base[0], rel, base[1]]
         staged = DeviceProblem(dm, tasks, W.limit_specs(model, True))
         assert staged.staged
-        os.environ["MK_NO_STAGED"] = "1"
-        try:
+        with L.options(staged=0):
             general = DeviceProblem(dm, tasks, W.limit_specs(model, True))
-        finally:
-            del os.environ["MK_NO_STAGED"]
         tq = dev(W.sample_q(model, rng, B))
         t_world = dm.frame_pose(tq, 2, model.site_id("pinch_site"))
         t_rel = dm.frame_pose(dev(W.sample_q(model, rng, B)), 2, model.site_id("pinch_site"))

@@ -82,11 +82,8 @@ def inputs(model, dm, n, seed, near=HAND):
 
 
 def solve_general(dm, tasks, limits, q, tg):
-    os.environ["MK_NO_STAGED"] = "1"
-    try:
+    with L.options(staged=0):
         general = DeviceProblem(dm, tasks, limits)
-    finally:
-        del os.environ["MK_NO_STAGED"]
     assert not general.staged
     return general.solve(q, tg, DT, DAMPING), general
 
@@ -113,22 +110,16 @@ def test_lane_rows_stage_on_gripper_arm(env, groups, expect_left):
     P, c, G, h = general.build_qp(q, tg, DT, DAMPING)
     npair = len(limits[2]["index"]) // 2
     in_range = torch.isfinite(h[:, -npair:]).sum(dim=1)
-    os.environ["MK_NO_GENERAL_STAGE"] = "1"
-    try:
+    with L.options(general_stage=0):
         v_l, st_l = staged.solve(q, tg, DT, DAMPING)
-    finally:
-        del os.environ["MK_NO_GENERAL_STAGE"]
     left = st_l != 0
     print("rows in range per problem:", torch.bincount(in_range).tolist(), "left to the general kernel:", int(left.sum()))
     assert float((in_range > 0).double().mean()) > 0.3
     if expect_left == "few":
         assert not bool((left & (in_range == 0)).any())
     # collision rows bind for a good share of the problems the lane stage finished
-    os.environ["MK_NO_STAGED"] = "1"
-    try:
+    with L.options(staged=0):
         free = DeviceProblem(dm, tasks, limits[:2])
-    finally:
-        del os.environ["MK_NO_STAGED"]
     v_f, _ = free.solve(q, tg, DT, DAMPING)
     binding = ((v_f - v_g).abs().amax(dim=1) > 1e-6) & ~left
     print("finished by the lane stage with a binding row:", int(binding.sum()))
@@ -189,11 +180,8 @@ def test_staged_loop_matches_general_loop(near):
         tg = torch.cat([t_world, (SE3(t_base).inverse() @ SE3(t_world)).wxyz_xyz], dim=1).contiguous()
     staged = DeviceProblem(dm, tasks, limits)
     assert staged.staged
-    os.environ["MK_NO_STAGED"] = "1"
-    try:
+    with L.options(staged=0):
         general = DeviceProblem(dm, tasks, limits)
-    finally:
-        del os.environ["MK_NO_STAGED"]
     qa, qb = q.clone(), q.clone()
     ra = staged.iterate_(qa, tg, W.DT, W.DAMPING, 12, 1e-4, 1e-4, want_v=True)
     rb = general.iterate_(qb, tg, W.DT, W.DAMPING, 12, 1e-4, 1e-4, want_v=True)
@@ -231,11 +219,8 @@ def test_staged_solve_with_pairs_without_closed_form(env):
     fin = torch.isfinite(h[:, -npair:])
     convex_cols = [k for k, (a, b) in enumerate(names) if "can_geom" in (a, b) or "egg" in (a, b)]
     assert int(fin[:, convex_cols].sum()) > 200          # rows of such pairs are in range for many problems
-    os.environ["MK_NO_GENERAL_STAGE"] = "1"
-    try:
+    with L.options(general_stage=0):
         _, st_l = staged.solve(q, tg, DT, DAMPING)
-    finally:
-        del os.environ["MK_NO_GENERAL_STAGE"]
     left = st_l != 0
     assert bool(left[fin[:, convex_cols].any(dim=1)].all())      # every one of them went to the general kernel
     assert int((~left).sum()) > B // 4                           # and the rest did not
@@ -261,11 +246,8 @@ def test_staged_solve_with_geoms_on_inner_links(env):
     P, c, G, h = general.build_qp(q, tg, DT, DAMPING)
     npair = len(limits[2]["index"]) // 2
     in_range = torch.isfinite(h[:, -npair:]).sum(dim=1)
-    os.environ["MK_NO_GENERAL_STAGE"] = "1"
-    try:
+    with L.options(general_stage=0):
         v_l, st_l = staged.solve(q, tg, DT, DAMPING)
-    finally:
-        del os.environ["MK_NO_GENERAL_STAGE"]
     left = st_l != 0
     print("rows in range per problem:", torch.bincount(in_range).tolist(), "left to the general kernel:", int(left.sum()))
     assert float((in_range > 0).double().mean()) > 0.3
@@ -334,12 +316,9 @@ def test_staged_solve_with_mesh_geoms_on_tidybot_arm_links():
     assert float(d.max()) <= 1e-9
     P, c, G, h = general.build_qp(tq, tg, DT, DAMPING)
     in_range = torch.isfinite(h[:, -npair:]).any(dim=1)
-    os.environ["MK_NO_GENERAL_STAGE"] = "1"
-    try:
+    with L.options(general_stage=0):
         _, st_l = staged.solve(tq, tg, DT, DAMPING)
-    finally:
-        del os.environ["MK_NO_GENERAL_STAGE"]
-    left = (st_l & (1 << 30)) != 0
+    left = st_l == 1   # without the last stage, what it would have solved reports status 1
     print("rows in range:", int(in_range.sum()), "left to the general kernel:", int(left.sum()), "of", B)
     assert int(in_range.sum()) > B // 10
     assert bool(left[in_range].all())            # the screen never drops a problem with a row in range

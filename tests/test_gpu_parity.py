@@ -17,6 +17,14 @@ pytestmark = pytest.mark.gpu
 V_TOL = 1e-9
 
 
+@pytest.fixture(autouse=True, params=["lane", "coop"])
+def kernel_form(request):
+    """Every test of this module runs twice: with the problems of the fused path on the
+    lane-per-problem kernels (mk_fused.hip) and on the cooperative ones (mk_coop.hip)."""
+    with L.options(coop=1 if request.param == "coop" else 0):
+        yield request.param
+
+
 @pytest.fixture(scope="module")
 def env():
     from mink_amd.engine import DeviceModel

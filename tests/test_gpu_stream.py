@@ -15,7 +15,6 @@ from mink_amd.mjcf import load_builtin
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-KNOB = "MK_FUSED_STREAM_BLOCKS"
 
 
 @pytest.fixture(scope="module")
@@ -33,17 +32,11 @@ def near_inputs(model, dm, n, seed):
 
 
 def run(prob, q0, tg, max_iters, knob):
-    old = os.environ.get(KNOB)
-    os.environ[KNOB] = str(knob)
-    try:
+    # (coop = 0: this module compares the two lane-per-problem kernels with each other)
+    with L.options(stream_blocks=int(knob), coop=0):
         q = q0.clone()
         res = prob.iterate_(q, tg, W.DT, W.DAMPING, max_iters, 1e-4, 1e-4, want_v=True)
         torch.cuda.synchronize()
-    finally:
-        if old is None:
-            del os.environ[KNOB]
-        else:
-            os.environ[KNOB] = old
     return q, res
 
 

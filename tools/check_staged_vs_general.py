@@ -1,6 +1,7 @@
 """One-off check: staged solve against the general kernel alone on large config-4 batches."""
 import os, sys
 import torch
+from mink_amd import _lib as L
 from mink_amd import workloads as W
 from mink_amd.engine import DeviceModel, DeviceProblem
 from mink_amd.mjcf import load_builtin
@@ -10,9 +11,8 @@ dev = torch.device("cuda:0")
 dm = DeviceModel(model, dev)
 tasks, limits = W.config4_specs(model)
 staged = DeviceProblem(dm, tasks, limits)
-os.environ["MK_NO_STAGED"] = "1"
-general = DeviceProblem(dm, tasks, limits)
-del os.environ["MK_NO_STAGED"]
+with L.options(staged=0):
+    general = DeviceProblem(dm, tasks, limits)
 n = 262144
 for seed in (1, 2, 3):
     for near in (0.25, 1.0):

@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, "tests")
 import numpy as np, torch
 import test_gpu_lane_rows as T
+from mink_amd import _lib as L
 from mink_amd.engine import DeviceModel, DeviceProblem
 from mink_amd.mjcf import load_mjcf
 model = load_mjcf("tests/models/grip_arm.xml")
@@ -11,9 +12,8 @@ groups = [(["pad_a", "pad_b"], ["brick_geom", "floor", "pillar"]), (["tip_b"], [
 tasks, limits = T.specs(model, groups)
 q, tg = T.inputs(model, dm, 6144, 21)
 staged = DeviceProblem(dm, tasks, limits)
-os.environ["MK_NO_GENERAL_STAGE"] = "1"
-v, st = staged.solve(q, tg, T.DT, T.DAMPING)
-del os.environ["MK_NO_GENERAL_STAGE"]
+with L.options(general_stage=0):
+    v, st = staged.solve(q, tg, T.DT, T.DAMPING)
 left = torch.nonzero(st != 0)[:, 0]
 vf, sf = staged.solve(q, tg, T.DT, T.DAMPING)
 np.savez("gpurun_out/left.npz", q=q[left].cpu().numpy(), tg=tg[left].cpu().numpy(), v=vf[left].cpu().numpy())

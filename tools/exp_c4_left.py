@@ -1,10 +1,11 @@
 """Experiment: which config-4 problems does the lane-per-problem rows stage hand on to the general kernel?"""
-import os
-os.environ["MK_NO_GENERAL_STAGE"] = "1"
+from mink_amd import _lib as L
 import torch
 from mink_amd import workloads as W
 from mink_amd.engine import DeviceModel, DeviceProblem
 from mink_amd.mjcf import load_builtin
+
+L.set_option("general_stage", 0)
 
 model = load_builtin("tidybot_cube")
 dev = torch.device("cuda:0")

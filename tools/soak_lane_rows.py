@@ -6,6 +6,7 @@ general kernel alone, over many seeds.  Uses the set-up of tests/test_gpu_lane_r
 import os
 import sys
 
+from mink_amd import _lib as L
 import torch
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -25,9 +26,8 @@ worst = 0.0
 for gname, groups in GROUPS.items():
     tasks, limits = T.specs(model, groups)
     staged = DeviceProblem(dm, tasks, limits)
-    os.environ["MK_NO_STAGED"] = "1"
-    general = DeviceProblem(dm, tasks, limits)
-    del os.environ["MK_NO_STAGED"]
+    with L.options(staged=0):
+        general = DeviceProblem(dm, tasks, limits)
     assert staged.staged and not general.staged
     for seed in range(100, 100 + SEEDS):
         q, tg = T.inputs(model, dm, B, seed)

@@ -7,6 +7,7 @@ import os
 import sys
 
 import numpy as np
+from mink_amd import _lib as L
 import torch
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -44,9 +45,8 @@ for k in range(SETS):
     coll["collision_detection_distance"] = float(coll["minimum_distance_from_collisions"] + rng.choice([0.005, 0.03, 0.1]))
     near = float(rng.choice([0.25, 1.0]))
     staged = DeviceProblem(dm, tasks, limits)
-    os.environ["MK_NO_STAGED"] = "1"
-    general = DeviceProblem(dm, tasks, limits)
-    del os.environ["MK_NO_STAGED"]
+    with L.options(staged=0):
+        general = DeviceProblem(dm, tasks, limits)
     assert staged.staged and not general.staged
     q, t = W.config4_inputs(model, dm, B, 1000 + k, near_fraction=near)
     vs, ss = staged.solve(q, t, dt, damping)

@@ -7,6 +7,7 @@ import os
 import sys
 
 import numpy as np
+from mink_amd import _lib as L
 import torch
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -31,13 +32,11 @@ for k in range(SETS):
     tg = torch.tensor(W.offset_targets(dm.frame_pose(q0, 2, site).cpu().numpy(), rng), device=S.dev)
     max_iters = int(rng.choice([5, 20]))
     res = []
-    for knob in (None, "0"):
-        if knob is not None:
-            os.environ["MK_FUSED_STREAM_BLOCKS"] = knob
-        q = q0.clone()
-        r = prob.iterate_(q, tg, p["dt"], p["damping"], max_iters, 1e-4, 1e-4, want_v=True)
-        torch.cuda.synchronize()
-        os.environ.pop("MK_FUSED_STREAM_BLOCKS", None)
+    for knob in (-1, 0):
+        with L.options(stream_blocks=knob, coop=0):
+            q = q0.clone()
+            r = prob.iterate_(q, tg, p["dt"], p["damping"], max_iters, 1e-4, 1e-4, want_v=True)
+            torch.cuda.synchronize()
         res.append((q, r))
     (qa, ra), (qb, rb) = res
     same = (torch.equal(qa, qb) and torch.equal(ra["iters"], rb["iters"]) and torch.equal(ra["status"], rb["status"])

@@ -1,5 +1,5 @@
 """Timing of benchmark config 4 (Frame + RelativeFrame + Posture, Cfg + Vel + Collision) through the
-staged solve.  MK_NO_LANE_ROWS=1 skips the lane-per-problem rows stage (A/B)."""
+staged solve.  option "lane_rows" = 0 skips the lane-per-problem rows stage (A/B)."""
 import sys, time
 import torch
 from mink_amd import workloads as W

@@ -1,11 +1,13 @@
 """Timing of the wave-per-problem kernel on benchmark config 4 (staging off), with and without
 the collision limit; MINK_AMD_LIB selects a tuning build of the library."""
 import os, sys, time
-os.environ["MK_NO_STAGED"] = "1"
+from mink_amd import _lib as L
 import torch
 from mink_amd import workloads as W
 from mink_amd.engine import DeviceModel, DeviceProblem
 from mink_amd.mjcf import load_builtin
+
+L.set_option("staged", 0)
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 model = load_builtin("tidybot_cube")

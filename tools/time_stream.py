@@ -1,6 +1,6 @@
 """Tuning helper (GPU): time of the near-target early-exit loop at 2^20 problems for the
 block-per-64 kernel and for the lane-streaming kernel at several refill thresholds / numbers of
-persistent waves (MK_FUSED_STREAM_BLOCKS / MK_FUSED_STREAM_REFILL)."""
+persistent waves (options "stream_blocks" / "stream_refill")."""
 import os
 import sys
 import time
@@ -30,9 +30,9 @@ qs = [q0.clone() for _ in range(4)]
 
 
 def run(env):
-    for k in ("MK_FUSED_STREAM_BLOCKS", "MK_FUSED_STREAM_REFILL"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
+    L.set_option("stream_blocks", env.get("stream_blocks", -1))
+    L.set_option("stream_refill", env.get("stream_refill", 16))
+    L.set_option("coop", 0)
     for b in qs:
         b.copy_(q0)
     prob.iterate_(qs[0], tg, W.DT, W.DAMPING, 20, 1e-4, 1e-4, out=out)
@@ -46,7 +46,7 @@ def run(env):
     print(f"{env}: {ms:.3f} ms  {solves / ms / 1e6:.2f} G solves/s  mean iters {solves / B:.2f}", flush=True)
 
 
-run({"MK_FUSED_STREAM_BLOCKS": "0"})
-for blocks in ("1024", "2048"):
-    for refill in ("1", "4", "8", "16", "24", "32", "48"):
-        run({"MK_FUSED_STREAM_BLOCKS": blocks, "MK_FUSED_STREAM_REFILL": refill})
+run({"stream_blocks": 0})
+for blocks in (1024, 2048):
+    for refill in (1, 4, 8, 16, 24, 32, 48):
+        run({"stream_blocks": blocks, "stream_refill": refill})
