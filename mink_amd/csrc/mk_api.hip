@@ -28,7 +28,7 @@ struct MkOptionEntry {
 };
 const MkOptionEntry kOptions[MK_OPT_COUNT] = {
     {"staged", 1},        {"lane_rows", 1},     {"general_stage", 1}, {"staged_loop", 1},        {"stream_blocks", -1},
-    {"stream_refill", 16}, {"coop", -1},        {"coop_max_batch", 16384}, {"coop_refine", 0},
+    {"stream_refill", 16}, {"coop", -1},        {"coop_max_batch", 16384}, {"handoff", -1},
 };
 std::atomic<long>* option_table() {
   static std::atomic<long> table[MK_OPT_COUNT];
@@ -43,13 +43,17 @@ std::atomic<long>* option_table() {
 long mk_opt(MkOption o) { return option_table()[o].load(std::memory_order_relaxed); }
 
 // ---- launchers implemented in mk_coop.hip ----
-hipError_t mk_coop_launch_step(int nc, bool refine, const MkFusedDesc* d_desc, const double* q, const double* targets,
+hipError_t mk_coop_launch_step(int nc, const MkFusedDesc* d_desc, const double* q, const double* targets,
                                int target_stride, double dt, double damping, int B, double* v, int32_t* status,
                                hipStream_t stream);
-hipError_t mk_coop_launch_iterate(int nc, bool refine, const MkFusedDesc* d_desc, double* q, const double* targets,
+hipError_t mk_coop_launch_iterate(int nc, const MkFusedDesc* d_desc, double* q, const double* targets,
                                   int target_stride, double dt, double damping, int B, int max_iters, double pos_tol,
                                   double ori_tol, double* v, int32_t* iters, double* err, int32_t* status,
                                   hipStream_t stream);
+hipError_t mk_coop_launch_resume(int nc, const MkFusedDesc* d_desc, double* q, const double* targets, int target_stride,
+                                 double dt, double damping, int B, int max_iters, double pos_tol, double ori_tol,
+                                 double* v, int32_t* iters, double* err, int32_t* status, int max_blocks,
+                                 hipStream_t stream);
 
 // ---- launchers implemented in mk_fused.hip ----
 hipError_t mk_fused_launch_step(int nc, const MkFusedDesc* d_desc, int nq, const double* q, const double* targets,
@@ -66,7 +70,7 @@ hipError_t mk_fused_launch_rows(int nc, const MkFusedDesc* d_desc, const MkFused
 hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, double* q, const double* targets,
                                    int target_stride, double dt, double damping, int B, int max_iters,
                                    double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
-                                   int32_t* status, hipStream_t stream);
+                                   int32_t* status, hipStream_t stream, int handoff_live, bool* handed);
 hipError_t mk_fused_launch_move_to(int nc, const MkFusedDesc* d_desc, int nq, double* q, const double* goals,
                                    double dt, double damping, int B, int max_steps, int max_iters, double pos_tol,
                                    double ori_tol, double wp_pos_thr, double wp_pos_step, double wp_rot_thr,
@@ -1232,7 +1236,7 @@ int mk_solve_ik_batch(const mk_problem* p, const double* d_q, const double* d_ta
     return MK_OK;
   }
   if (use_coop(p, B)) {
-    MK_HIP(mk_coop_launch_step(p->nc_kernel, mk_opt(MK_OPT_COOP_REFINE) != 0, p->d_fused, d_q, d_targets,
+    MK_HIP(mk_coop_launch_step(p->nc_kernel, p->d_fused, d_q, d_targets,
                                p->info.target_stride, dt, damping, B, d_v, d_status, static_cast<hipStream_t>(stream)));
     return MK_OK;
   }
@@ -1315,14 +1319,24 @@ int mk_solve_ik_iterate_batch(const mk_problem* p, double* d_q, const double* d_
     return MK_OK;
   }
   if (use_coop(p, B)) {
-    MK_HIP(mk_coop_launch_iterate(p->nc_kernel, mk_opt(MK_OPT_COOP_REFINE) != 0, p->d_fused, d_q, d_targets,
+    MK_HIP(mk_coop_launch_iterate(p->nc_kernel, p->d_fused, d_q, d_targets,
                                   p->info.target_stride, dt, damping, B, max_iters, pos_tol, ori_tol, d_v, d_iters, d_err,
                                   d_status, static_cast<hipStream_t>(stream)));
     return MK_OK;
   }
+  // With an exit test the lane-per-problem kernel hands the last few live problems of each wave to
+  // the cooperative kernel (second launch below); not for posture tasks with a Levenberg-Marquardt
+  // term, which the cooperative kernels do not carry.
+  long handoff = mk_opt(MK_OPT_HANDOFF);
+  if (handoff < 0) handoff = 4;
+  if (p->h_fused.any_posture_lm || mk_opt(MK_OPT_COOP) == 0) handoff = 0;
+  bool handed = false;
   MK_HIP(mk_fused_launch_iterate(p->nc_kernel, p->d_fused, p->info.nq, d_q, d_targets, p->info.target_stride, dt,
                                  damping, B, max_iters, pos_tol, ori_tol, d_v, d_iters, d_err, d_status,
-                                 static_cast<hipStream_t>(stream)));
+                                 static_cast<hipStream_t>(stream), (int)handoff, &handed));
+  if (handed)
+    MK_HIP(mk_coop_launch_resume(p->nc_kernel, p->d_fused, d_q, d_targets, p->info.target_stride, dt, damping, B, max_iters,
+                                 pos_tol, ori_tol, d_v, d_iters, d_err, d_status, 2048, static_cast<hipStream_t>(stream)));
   return MK_OK;
 }
 

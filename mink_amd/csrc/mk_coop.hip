@@ -118,6 +118,241 @@ __device__ double co_pick(double v, int src);
 __device__ uint32_t co_ballot(bool p);
 #endif
 
+// ---- compound row operations: the broadcast fused into the multiply-add ----
+// gfx950 has 64-bit DPP forms of v_fmac_f64 and v_mov_b64 for row_newbcast, so "multiply my
+// value by lane J's and accumulate" is ONE instruction where a broadcast through 32-bit DPP
+// moves costs three.  The compiler has no builtin for them; they are issued from inline
+// assembly in blocks that start with `s_nop 1`: a DPP instruction must not read a register
+// that a vector instruction wrote within the previous two issue slots, and the compiler pads
+// nothing inside or in front of an asm statement.  Within a block no instruction reads through
+// DPP what an earlier one of the block wrote, except where a nop is written between them.
+// Read-write operands are early-clobber so that no plain input shares their register.
+// MK_COOP_PLAIN_DPP builds the same operations from co_bcast (A/B timing, and the host emulation).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MK_COOP_PLAIN_DPP)
+#define MK_CO_ASM 1
+#define MK_CO_DPPT " row_mask:0xf bank_mask:0xf\n\t"
+#define MK_CO_ELIM(n) "v_fmac_f64_dpp %[a" #n "], %[a" #n "], %[f] row_newbcast:%[j]" MK_CO_DPPT
+#define MK_CO_DOT(n) "v_fmac_f64_dpp %[y], %[x], %[h" #n "] row_newbcast:%[k" #n "]" MK_CO_DPPT
+#define MK_CO_GRAM(n) "v_fmac_f64_dpp %[h], %[w" #n "], %[w" #n "] row_newbcast:%[k]" MK_CO_DPPT
+#define MK_CO_MOV(n) "v_mov_b64_dpp %[o" #n "], %[i" #n "] row_newbcast:%[j]" MK_CO_DPPT
+#define MK_CO_NEXT "v_mov_b64_dpp %[nx], %[a0] row_newbcast:%[jn]" MK_CO_DPPT
+#define MK_CO_CHAIN(n) "s_nop 1\n\tv_fmac_f64_dpp %[r], %[r], %[f" #n "] row_newbcast:%[k" #n "]" MK_CO_DPPT
+#endif
+
+// a[k] += (a[k] of lane J) * f for k in [K0, K1): the elimination of one pivot on this lane's row.
+template <int J, int K0, int K1, int M>
+MK_CO void co_elim(double (&a)[M], double f) {
+  if constexpr (K0 < K1) {
+#if defined(MK_CO_ASM)
+    constexpr int N = K1 - K0 < 4 ? K1 - K0 : 4;
+    if constexpr (N == 4)
+      asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) MK_CO_ELIM(1) MK_CO_ELIM(2) MK_CO_ELIM(3)
+                   : [a0] "+&v"(a[K0]), [a1] "+&v"(a[K0 + 1]), [a2] "+&v"(a[K0 + 2]), [a3] "+&v"(a[K0 + 3])
+                   : [f] "v"(f), [j] "n"(J));
+    else if constexpr (N == 3)
+      asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) MK_CO_ELIM(1) MK_CO_ELIM(2)
+                   : [a0] "+&v"(a[K0]), [a1] "+&v"(a[K0 + 1]), [a2] "+&v"(a[K0 + 2])
+                   : [f] "v"(f), [j] "n"(J));
+    else if constexpr (N == 2)
+      asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) MK_CO_ELIM(1)
+                   : [a0] "+&v"(a[K0]), [a1] "+&v"(a[K0 + 1])
+                   : [f] "v"(f), [j] "n"(J));
+    else
+      asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) : [a0] "+&v"(a[K0]) : [f] "v"(f), [j] "n"(J));
+    co_elim<J, K0 + N, K1>(a, f);
+#else
+    co_for<K0, K1>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      a[k] = fma(co_bcast<J>(a[k]), f, a[k]);
+    });
+#endif
+  }
+}
+
+// One pivot of the elimination as a single block: a[K0 + i] += (a[K0 + i] of lane J) * f for i in
+// [0, N), then `next` = a[K0] of lane J + 1, the next pivot (a[K0] is written first, so the
+// broadcast that reads it comes at least two instructions later, or after a nop).
+template <int J, int K0, int N, int M>
+MK_CO void co_pivot(double (&a)[M], double f, double& next) {
+#if defined(MK_CO_ASM)
+  static_assert(N >= 1 && N <= 12, "row length");
+  if constexpr (N == 1)
+    asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) "s_nop 1\n\t" MK_CO_NEXT
+                 : [a0] "+&v"(a[K0 + 0]), [nx] "=&v"(next)
+                 : [f] "v"(f), [j] "n"(J), [jn] "n"(J + 1));
+  if constexpr (N == 2)
+    asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) MK_CO_ELIM(1) "s_nop 1\n\t" MK_CO_NEXT
+                 : [a0] "+&v"(a[K0 + 0]), [a1] "+&v"(a[K0 + 1]), [nx] "=&v"(next)
+                 : [f] "v"(f), [j] "n"(J), [jn] "n"(J + 1));
+  if constexpr (N == 3)
+    asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) MK_CO_ELIM(1) MK_CO_ELIM(2) MK_CO_NEXT
+                 : [a0] "+&v"(a[K0 + 0]), [a1] "+&v"(a[K0 + 1]), [a2] "+&v"(a[K0 + 2]), [nx] "=&v"(next)
+                 : [f] "v"(f), [j] "n"(J), [jn] "n"(J + 1));
+  if constexpr (N == 4)
+    asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) MK_CO_ELIM(1) MK_CO_ELIM(2) MK_CO_ELIM(3) MK_CO_NEXT
+                 : [a0] "+&v"(a[K0 + 0]), [a1] "+&v"(a[K0 + 1]), [a2] "+&v"(a[K0 + 2]), [a3] "+&v"(a[K0 + 3]), [nx] "=&v"(next)
+                 : [f] "v"(f), [j] "n"(J), [jn] "n"(J + 1));
+  if constexpr (N == 5)
+    asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) MK_CO_ELIM(1) MK_CO_ELIM(2) MK_CO_ELIM(3) MK_CO_ELIM(4) MK_CO_NEXT
+                 : [a0] "+&v"(a[K0 + 0]), [a1] "+&v"(a[K0 + 1]), [a2] "+&v"(a[K0 + 2]), [a3] "+&v"(a[K0 + 3]), [a4] "+&v"(a[K0 + 4]), [nx] "=&v"(next)
+                 : [f] "v"(f), [j] "n"(J), [jn] "n"(J + 1));
+  if constexpr (N == 6)
+    asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) MK_CO_ELIM(1) MK_CO_ELIM(2) MK_CO_ELIM(3) MK_CO_ELIM(4) MK_CO_ELIM(5) MK_CO_NEXT
+                 : [a0] "+&v"(a[K0 + 0]), [a1] "+&v"(a[K0 + 1]), [a2] "+&v"(a[K0 + 2]), [a3] "+&v"(a[K0 + 3]), [a4] "+&v"(a[K0 + 4]), [a5] "+&v"(a[K0 + 5]), [nx] "=&v"(next)
+                 : [f] "v"(f), [j] "n"(J), [jn] "n"(J + 1));
+  if constexpr (N == 7)
+    asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) MK_CO_ELIM(1) MK_CO_ELIM(2) MK_CO_ELIM(3) MK_CO_ELIM(4) MK_CO_ELIM(5) MK_CO_ELIM(6) MK_CO_NEXT
+                 : [a0] "+&v"(a[K0 + 0]), [a1] "+&v"(a[K0 + 1]), [a2] "+&v"(a[K0 + 2]), [a3] "+&v"(a[K0 + 3]), [a4] "+&v"(a[K0 + 4]), [a5] "+&v"(a[K0 + 5]), [a6] "+&v"(a[K0 + 6]), [nx] "=&v"(next)
+                 : [f] "v"(f), [j] "n"(J), [jn] "n"(J + 1));
+  if constexpr (N == 8)
+    asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) MK_CO_ELIM(1) MK_CO_ELIM(2) MK_CO_ELIM(3) MK_CO_ELIM(4) MK_CO_ELIM(5) MK_CO_ELIM(6) MK_CO_ELIM(7) MK_CO_NEXT
+                 : [a0] "+&v"(a[K0 + 0]), [a1] "+&v"(a[K0 + 1]), [a2] "+&v"(a[K0 + 2]), [a3] "+&v"(a[K0 + 3]), [a4] "+&v"(a[K0 + 4]), [a5] "+&v"(a[K0 + 5]), [a6] "+&v"(a[K0 + 6]), [a7] "+&v"(a[K0 + 7]), [nx] "=&v"(next)
+                 : [f] "v"(f), [j] "n"(J), [jn] "n"(J + 1));
+  if constexpr (N == 9)
+    asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) MK_CO_ELIM(1) MK_CO_ELIM(2) MK_CO_ELIM(3) MK_CO_ELIM(4) MK_CO_ELIM(5) MK_CO_ELIM(6) MK_CO_ELIM(7) MK_CO_ELIM(8) MK_CO_NEXT
+                 : [a0] "+&v"(a[K0 + 0]), [a1] "+&v"(a[K0 + 1]), [a2] "+&v"(a[K0 + 2]), [a3] "+&v"(a[K0 + 3]), [a4] "+&v"(a[K0 + 4]), [a5] "+&v"(a[K0 + 5]), [a6] "+&v"(a[K0 + 6]), [a7] "+&v"(a[K0 + 7]), [a8] "+&v"(a[K0 + 8]), [nx] "=&v"(next)
+                 : [f] "v"(f), [j] "n"(J), [jn] "n"(J + 1));
+  if constexpr (N == 10)
+    asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) MK_CO_ELIM(1) MK_CO_ELIM(2) MK_CO_ELIM(3) MK_CO_ELIM(4) MK_CO_ELIM(5) MK_CO_ELIM(6) MK_CO_ELIM(7) MK_CO_ELIM(8) MK_CO_ELIM(9) MK_CO_NEXT
+                 : [a0] "+&v"(a[K0 + 0]), [a1] "+&v"(a[K0 + 1]), [a2] "+&v"(a[K0 + 2]), [a3] "+&v"(a[K0 + 3]), [a4] "+&v"(a[K0 + 4]), [a5] "+&v"(a[K0 + 5]), [a6] "+&v"(a[K0 + 6]), [a7] "+&v"(a[K0 + 7]), [a8] "+&v"(a[K0 + 8]), [a9] "+&v"(a[K0 + 9]), [nx] "=&v"(next)
+                 : [f] "v"(f), [j] "n"(J), [jn] "n"(J + 1));
+  if constexpr (N == 11)
+    asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) MK_CO_ELIM(1) MK_CO_ELIM(2) MK_CO_ELIM(3) MK_CO_ELIM(4) MK_CO_ELIM(5) MK_CO_ELIM(6) MK_CO_ELIM(7) MK_CO_ELIM(8) MK_CO_ELIM(9) MK_CO_ELIM(10) MK_CO_NEXT
+                 : [a0] "+&v"(a[K0 + 0]), [a1] "+&v"(a[K0 + 1]), [a2] "+&v"(a[K0 + 2]), [a3] "+&v"(a[K0 + 3]), [a4] "+&v"(a[K0 + 4]), [a5] "+&v"(a[K0 + 5]), [a6] "+&v"(a[K0 + 6]), [a7] "+&v"(a[K0 + 7]), [a8] "+&v"(a[K0 + 8]), [a9] "+&v"(a[K0 + 9]), [a10] "+&v"(a[K0 + 10]), [nx] "=&v"(next)
+                 : [f] "v"(f), [j] "n"(J), [jn] "n"(J + 1));
+  if constexpr (N == 12)
+    asm volatile("s_nop 1\n\t" MK_CO_ELIM(0) MK_CO_ELIM(1) MK_CO_ELIM(2) MK_CO_ELIM(3) MK_CO_ELIM(4) MK_CO_ELIM(5) MK_CO_ELIM(6) MK_CO_ELIM(7) MK_CO_ELIM(8) MK_CO_ELIM(9) MK_CO_ELIM(10) MK_CO_ELIM(11) MK_CO_NEXT
+                 : [a0] "+&v"(a[K0 + 0]), [a1] "+&v"(a[K0 + 1]), [a2] "+&v"(a[K0 + 2]), [a3] "+&v"(a[K0 + 3]), [a4] "+&v"(a[K0 + 4]), [a5] "+&v"(a[K0 + 5]), [a6] "+&v"(a[K0 + 6]), [a7] "+&v"(a[K0 + 7]), [a8] "+&v"(a[K0 + 8]), [a9] "+&v"(a[K0 + 9]), [a10] "+&v"(a[K0 + 10]), [a11] "+&v"(a[K0 + 11]), [nx] "=&v"(next)
+                 : [f] "v"(f), [j] "n"(J), [jn] "n"(J + 1));
+#else
+  co_for<K0, K0 + N>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    a[k] = fma(co_bcast<J>(a[k]), f, a[k]);
+  });
+  next = co_bcast<(J + 1) % kRow>(a[K0]);
+#endif
+}
+
+// y += sum over k in [0, N) of (x of lane k) * h[k]: this lane's entry of a matrix-vector product
+// with the vector spread over the row.
+template <int N>
+MK_CO void co_dot(double& y, double x, const double (&h)[N]) {
+#if defined(MK_CO_ASM)
+  static_assert(N >= 1 && N <= 12, "row length");
+  if constexpr (N == 1)
+    asm volatile("s_nop 1\n\t" MK_CO_DOT(0)
+                 : [y] "+&v"(y)
+                 : [x] "v"(x), [h0] "v"(h[0]), [k0] "n"(0));
+  if constexpr (N == 2)
+    asm volatile("s_nop 1\n\t" MK_CO_DOT(0) MK_CO_DOT(1)
+                 : [y] "+&v"(y)
+                 : [x] "v"(x), [h0] "v"(h[0]), [h1] "v"(h[1]), [k0] "n"(0), [k1] "n"(1));
+  if constexpr (N == 3)
+    asm volatile("s_nop 1\n\t" MK_CO_DOT(0) MK_CO_DOT(1) MK_CO_DOT(2)
+                 : [y] "+&v"(y)
+                 : [x] "v"(x), [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [k0] "n"(0), [k1] "n"(1), [k2] "n"(2));
+  if constexpr (N == 4)
+    asm volatile("s_nop 1\n\t" MK_CO_DOT(0) MK_CO_DOT(1) MK_CO_DOT(2) MK_CO_DOT(3)
+                 : [y] "+&v"(y)
+                 : [x] "v"(x), [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [k0] "n"(0), [k1] "n"(1), [k2] "n"(2), [k3] "n"(3));
+  if constexpr (N == 5)
+    asm volatile("s_nop 1\n\t" MK_CO_DOT(0) MK_CO_DOT(1) MK_CO_DOT(2) MK_CO_DOT(3) MK_CO_DOT(4)
+                 : [y] "+&v"(y)
+                 : [x] "v"(x), [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [h4] "v"(h[4]), [k0] "n"(0), [k1] "n"(1), [k2] "n"(2), [k3] "n"(3), [k4] "n"(4));
+  if constexpr (N == 6)
+    asm volatile("s_nop 1\n\t" MK_CO_DOT(0) MK_CO_DOT(1) MK_CO_DOT(2) MK_CO_DOT(3) MK_CO_DOT(4) MK_CO_DOT(5)
+                 : [y] "+&v"(y)
+                 : [x] "v"(x), [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [h4] "v"(h[4]), [h5] "v"(h[5]), [k0] "n"(0), [k1] "n"(1), [k2] "n"(2), [k3] "n"(3), [k4] "n"(4), [k5] "n"(5));
+  if constexpr (N == 7)
+    asm volatile("s_nop 1\n\t" MK_CO_DOT(0) MK_CO_DOT(1) MK_CO_DOT(2) MK_CO_DOT(3) MK_CO_DOT(4) MK_CO_DOT(5) MK_CO_DOT(6)
+                 : [y] "+&v"(y)
+                 : [x] "v"(x), [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [h4] "v"(h[4]), [h5] "v"(h[5]), [h6] "v"(h[6]), [k0] "n"(0), [k1] "n"(1), [k2] "n"(2), [k3] "n"(3), [k4] "n"(4), [k5] "n"(5), [k6] "n"(6));
+  if constexpr (N == 8)
+    asm volatile("s_nop 1\n\t" MK_CO_DOT(0) MK_CO_DOT(1) MK_CO_DOT(2) MK_CO_DOT(3) MK_CO_DOT(4) MK_CO_DOT(5) MK_CO_DOT(6) MK_CO_DOT(7)
+                 : [y] "+&v"(y)
+                 : [x] "v"(x), [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [h4] "v"(h[4]), [h5] "v"(h[5]), [h6] "v"(h[6]), [h7] "v"(h[7]), [k0] "n"(0), [k1] "n"(1), [k2] "n"(2), [k3] "n"(3), [k4] "n"(4), [k5] "n"(5), [k6] "n"(6), [k7] "n"(7));
+  if constexpr (N == 9)
+    asm volatile("s_nop 1\n\t" MK_CO_DOT(0) MK_CO_DOT(1) MK_CO_DOT(2) MK_CO_DOT(3) MK_CO_DOT(4) MK_CO_DOT(5) MK_CO_DOT(6) MK_CO_DOT(7) MK_CO_DOT(8)
+                 : [y] "+&v"(y)
+                 : [x] "v"(x), [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [h4] "v"(h[4]), [h5] "v"(h[5]), [h6] "v"(h[6]), [h7] "v"(h[7]), [h8] "v"(h[8]), [k0] "n"(0), [k1] "n"(1), [k2] "n"(2), [k3] "n"(3), [k4] "n"(4), [k5] "n"(5), [k6] "n"(6), [k7] "n"(7), [k8] "n"(8));
+  if constexpr (N == 10)
+    asm volatile("s_nop 1\n\t" MK_CO_DOT(0) MK_CO_DOT(1) MK_CO_DOT(2) MK_CO_DOT(3) MK_CO_DOT(4) MK_CO_DOT(5) MK_CO_DOT(6) MK_CO_DOT(7) MK_CO_DOT(8) MK_CO_DOT(9)
+                 : [y] "+&v"(y)
+                 : [x] "v"(x), [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [h4] "v"(h[4]), [h5] "v"(h[5]), [h6] "v"(h[6]), [h7] "v"(h[7]), [h8] "v"(h[8]), [h9] "v"(h[9]), [k0] "n"(0), [k1] "n"(1), [k2] "n"(2), [k3] "n"(3), [k4] "n"(4), [k5] "n"(5), [k6] "n"(6), [k7] "n"(7), [k8] "n"(8), [k9] "n"(9));
+  if constexpr (N == 11)
+    asm volatile("s_nop 1\n\t" MK_CO_DOT(0) MK_CO_DOT(1) MK_CO_DOT(2) MK_CO_DOT(3) MK_CO_DOT(4) MK_CO_DOT(5) MK_CO_DOT(6) MK_CO_DOT(7) MK_CO_DOT(8) MK_CO_DOT(9) MK_CO_DOT(10)
+                 : [y] "+&v"(y)
+                 : [x] "v"(x), [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [h4] "v"(h[4]), [h5] "v"(h[5]), [h6] "v"(h[6]), [h7] "v"(h[7]), [h8] "v"(h[8]), [h9] "v"(h[9]), [h10] "v"(h[10]), [k0] "n"(0), [k1] "n"(1), [k2] "n"(2), [k3] "n"(3), [k4] "n"(4), [k5] "n"(5), [k6] "n"(6), [k7] "n"(7), [k8] "n"(8), [k9] "n"(9), [k10] "n"(10));
+  if constexpr (N == 12)
+    asm volatile("s_nop 1\n\t" MK_CO_DOT(0) MK_CO_DOT(1) MK_CO_DOT(2) MK_CO_DOT(3) MK_CO_DOT(4) MK_CO_DOT(5) MK_CO_DOT(6) MK_CO_DOT(7) MK_CO_DOT(8) MK_CO_DOT(9) MK_CO_DOT(10) MK_CO_DOT(11)
+                 : [y] "+&v"(y)
+                 : [x] "v"(x), [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [h4] "v"(h[4]), [h5] "v"(h[5]), [h6] "v"(h[6]), [h7] "v"(h[7]), [h8] "v"(h[8]), [h9] "v"(h[9]), [h10] "v"(h[10]), [h11] "v"(h[11]), [k0] "n"(0), [k1] "n"(1), [k2] "n"(2), [k3] "n"(3), [k4] "n"(4), [k5] "n"(5), [k6] "n"(6), [k7] "n"(7), [k8] "n"(8), [k9] "n"(9), [k10] "n"(10), [k11] "n"(11));
+#else
+  co_for<0, N>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    y = fma(co_bcast<k>(x), h[k], y);
+  });
+#endif
+}
+
+// h += sum over r of (w[r] of lane K) * w[r]: entry K of this lane's row of w'w.
+template <int K>
+MK_CO void co_gram(double& h, const double (&w)[6]) {
+#if defined(MK_CO_ASM)
+  asm volatile("s_nop 1\n\t" MK_CO_GRAM(0) MK_CO_GRAM(1) MK_CO_GRAM(2) MK_CO_GRAM(3) MK_CO_GRAM(4) MK_CO_GRAM(5)
+               : [h] "+&v"(h)
+               : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]), [k] "n"(K));
+#else
+#pragma unroll
+  for (int r = 0; r < 6; ++r) h = fma(co_bcast<K>(w[r]), w[r], h);
+#endif
+}
+
+// r <- r + (r of lane k) * f[k] for k = K0 .. K1 - 1, one after the other (each step reads what
+// the previous one wrote): the eliminations of a factorisation repeated on a right-hand side.
+template <int K0, int K1, int M>
+MK_CO void co_replay(double& r, const double (&f)[M]) {
+  if constexpr (K0 < K1) {
+#if defined(MK_CO_ASM)
+    constexpr int N = K1 - K0 < 4 ? K1 - K0 : 4;
+    if constexpr (N == 4)
+      asm volatile(MK_CO_CHAIN(0) MK_CO_CHAIN(1) MK_CO_CHAIN(2) MK_CO_CHAIN(3)
+                   : [r] "+&v"(r)
+                   : [f0] "v"(f[K0]), [f1] "v"(f[K0 + 1]), [f2] "v"(f[K0 + 2]), [f3] "v"(f[K0 + 3]), [k0] "n"(K0),
+                     [k1] "n"(K0 + 1), [k2] "n"(K0 + 2), [k3] "n"(K0 + 3));
+    else if constexpr (N == 3)
+      asm volatile(MK_CO_CHAIN(0) MK_CO_CHAIN(1) MK_CO_CHAIN(2)
+                   : [r] "+&v"(r)
+                   : [f0] "v"(f[K0]), [f1] "v"(f[K0 + 1]), [f2] "v"(f[K0 + 2]), [k0] "n"(K0), [k1] "n"(K0 + 1),
+                     [k2] "n"(K0 + 2));
+    else if constexpr (N == 2)
+      asm volatile(MK_CO_CHAIN(0) MK_CO_CHAIN(1)
+                   : [r] "+&v"(r)
+                   : [f0] "v"(f[K0]), [f1] "v"(f[K0 + 1]), [k0] "n"(K0), [k1] "n"(K0 + 1));
+    else
+      asm volatile(MK_CO_CHAIN(0) : [r] "+&v"(r) : [f0] "v"(f[K0]), [k0] "n"(K0));
+    co_replay<K0 + N, K1>(r, f);
+#else
+    co_for<K0, K1>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      r = fma(co_bcast<k>(r), f[k], r);
+    });
+#endif
+  }
+}
+
+// value of lane J of the row, one 64-bit move
+template <int J>
+MK_CO double co_bcast64(double v) {
+#if defined(MK_CO_ASM)
+  double o;
+  asm volatile("s_nop 1\n\t" MK_CO_MOV(0) : [o0] "=v"(o) : [i0] "v"(v), [j] "n"(J));
+  return o;
+#else
+  return co_bcast<J>(v);
+#endif
+}
+
 struct CoPose {
   Q4 q;
   V3 t;
@@ -130,8 +365,18 @@ MK_CO CoPose co_up_pose(const CoPose& p) {   // identity beyond the row
 }
 template <int J>
 MK_CO CoPose co_bcast_pose(const CoPose& p) {
+#if defined(MK_CO_ASM)
+  CoPose o;
+  asm volatile("s_nop 1\n\t" MK_CO_MOV(0) MK_CO_MOV(1) MK_CO_MOV(2) MK_CO_MOV(3) MK_CO_MOV(4) MK_CO_MOV(5) MK_CO_MOV(6)
+               : [o0] "=&v"(o.q.w), [o1] "=&v"(o.q.x), [o2] "=&v"(o.q.y), [o3] "=&v"(o.q.z), [o4] "=&v"(o.t.x),
+                 [o5] "=&v"(o.t.y), [o6] "=&v"(o.t.z)
+               : [i0] "v"(p.q.w), [i1] "v"(p.q.x), [i2] "v"(p.q.y), [i3] "v"(p.q.z), [i4] "v"(p.t.x), [i5] "v"(p.t.y),
+                 [i6] "v"(p.t.z), [j] "n"(J));
+  return o;
+#else
   return CoPose{Q4{co_bcast<J>(p.q.w), co_bcast<J>(p.q.x), co_bcast<J>(p.q.y), co_bcast<J>(p.q.z)},
                 V3{co_bcast<J>(p.t.x), co_bcast<J>(p.t.y), co_bcast<J>(p.t.z)}};
+#endif
 }
 
 // Arg-max over the row: the largest value and the lowest lane that holds it, in every lane.
@@ -157,6 +402,9 @@ struct CoLane {
   int qadr, dof;          // the slot's coordinate and dof (dof < 0: padding slot or lane beyond the chain)
   double onehot[NC];      // 1 in entry l
   bool valid;             // l < NC
+  // the same in every lane (read once per launch, not once per iteration)
+  double cost[6], gain, lm;   // frame task
+  int nd, needs_diag, nfree;
 };
 
 template <int NC>
@@ -183,6 +431,13 @@ MK_CO void co_load_lane(const MkFusedDesc* __restrict__ D, CoLane<NC>& C) {
   C.dof = C.valid ? D->seg_dof[s] : -1;
 #pragma unroll
   for (int k = 0; k < NC; ++k) C.onehot[k] = (l == k) ? 1.0 : 0.0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) C.cost[r] = D->cost[r];
+  C.gain = D->gain;
+  C.lm = D->lm;
+  C.nd = D->nd;
+  C.needs_diag = D->needs_diag;
+  C.nfree = D->nfree;
 }
 
 // Chain kinematics across the row (mj_kinematics + mj_jacSite + the rotation into the body
@@ -222,67 +477,87 @@ MK_CO void co_chain(const CoLane<NC>& C, double qc, double (&Jc)[6], CoPose& W) 
   Jc[5] = h * R.m[8];
 }
 
-// Ji and Q of SE3.ljacinv(xi) = [[Ji, -Ji Q Ji], [0, Ji]] (mink/lie/se3.py:210-249,
-// mink/lie/so3.py:214-226); Ji = I, Q = 0 where the reference returns exactly I6.  A lane
-// applies the blocks to its own column as Ji (bl - Q (Ji ba)), which saves forming -Ji Q Ji.
-MK_CO void co_ljacinv_parts(Twist xi, M3& Ji, M3& Qm) {
-  const double t2 = dot(xi.w, xi.w);
+// Frame-task error e = log(T_wb^-1 T_wt) (mink/tasks/frame_task.py:95-122, mink/lie/se3.py:159-185)
+// of the frame at (Q, t) for the target (Qt, pt), together with Ji and Q of
+// SE3.ljacinv(e) = [[Ji, -Ji Q Ji], [0, Ji]] (mink/lie/se3.py:210-249, mink/lie/so3.py:214-226);
+// Ji = I, Q = 0 where the reference returns exactly I6.  A lane applies the blocks to its own
+// column as Ji (bl - Q (Ji ba)), which saves forming -Ji Q Ji.  Every lane evaluates the same
+// scalars, with one exception: SE3.log needs sin / cos of theta / 2 and the Jacobian those of
+// theta, and the two are one evaluation -- even lanes take theta / 2, odd lanes theta, and lanes
+// 0 and 1 hand the results to the row.
+MK_CO Twist co_frame_error_jlog(Q4 Q, V3 t, Q4 Qt, V3 pt, M3& Ji, M3& Qm) {
+  const M3 R = q2m(Q);
+  const V3 w = so3_log(qmul(qconj(Q), Qt));
+  const V3 te = mulT(R, pt - t);
+  const double t2 = dot(w, w);
+  const double t2s = fmax(t2, 1e-300);
+  const double rth = mk_rsqrt(t2s), th = t2s * rth;
+  double sn, cs;
+  mk_sincos((co_lane() & 1) ? th : 0.5 * th, &sn, &cs);
+  const double sh = co_bcast64<0>(sn), ch = co_bcast64<0>(cs);
+  const double coef_gen = (1.0 - th * ch * mk_rcp(2.0 * sh)) * (rth * rth);
+  const double coef = (t2 < MK_LIE_EPS) ? 1.0 / 12.0 : coef_gen;
+  const M3 Vinv = rodrigues_like(w, -0.5, coef);
+  const Twist e = Twist{mul(Vinv, te), w};
   if (t2 < MK_LIE_EPS) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) { Ji.m[i] = (i % 4 == 0) ? 1.0 : 0.0; Qm.m[i] = 0.0; }
-    return;
+    return e;
   }
-  const double rth = mk_rsqrt(t2), th = t2 * rth;
-  double s, c;
-  mk_sincos(th, &s, &c);
-  const double it2 = rth * rth;
-  const double A = it2 * (1.0 - (th * s * mk_rcp(2.0 * (1.0 - c))));
-  Ji = rodrigues_like(xi.w, -0.5, A);
-  Qm = se3_Q_closed(xi, t2, rth, th, s, c);
+  const double s = co_bcast64<1>(sn), c = co_bcast64<1>(cs);
+  // SO3.ljacinv switches on theta (not theta^2); theta >= 1e-5 here, so closed form.
+  const double A = (rth * rth) * (1.0 - (th * s * mk_rcp(2.0 * (1.0 - c))));
+  Ji = rodrigues_like(w, -0.5, A);
+  Qm = se3_Q_closed(e, t2, rth, th, s, c);
+  return e;
 }
 
-// Gauss-Jordan elimination, without pivoting, of the block of H on the free variables of the
-// row (H symmetric positive definite, so every pivot is positive): lane i holds row i.  With
-// pivot j every other free row subtracts f_ij times the pivot row; the multipliers and the
-// reciprocal of the lane's final diagonal are kept, so that a right-hand side is solved for by
-// repeating the eliminations on it (co_apply).  Rows and pivots of active variables take no part.
+// Gauss-Jordan elimination, without pivoting, of H with the rows and columns of the active
+// variables replaced by identity (H symmetric positive definite, so every pivot is positive):
+// lane i holds row i.  With pivot j every other row adds nf_ij = -A_ij / A_jj times the pivot
+// row; the multipliers and the reciprocal of the lane's final diagonal are kept, so that a
+// right-hand side is solved for by repeating the eliminations on it (co_apply; entries of active
+// variables must be zero there).  An active variable's row is e_i with a zero right-hand side:
+// as a pivot it changes nothing but its own (dead) column, and no pivot changes it.  The pivot
+// lane's own multiplier is fma(-A_jj, 1 / A_jj, 1), the rounding residual of the reciprocal
+// (a relative change of its row by 1e-16) instead of a lane test.
+// co_factor_solve eliminates a right-hand side along with the matrix and returns the solution.
 template <int NC>
 struct CoFactor {
-  double f[NC];
+  double nf[NC];
   double invd;
 };
 
 template <int NC>
-MK_CO void co_factor(const double (&H)[NC], const double (&onehot)[NC], uint32_t act, bool valid, CoFactor<NC>& F) {
-  const int l = co_lane();
-  double A[NC];
+MK_CO double co_factor_solve(const double (&H)[NC], const double (&onehot)[NC], uint32_t act, bool valid, double rhs,
+                             CoFactor<NC>& F) {
+  const bool a = ((act >> co_lane()) & 1u) != 0u;
+  double A[NC + 1];   // the lane's row, and its right-hand side as one more column
 #pragma unroll
-  for (int k = 0; k < NC; ++k) A[k] = H[k];
-  const uint32_t freem = ~act & ((1u << NC) - 1u);
-  // bit j: this lane's row is eliminated with pivot j (both free, j != l)
-  const uint32_t w = ((freem >> l) & 1u) ? (freem & ~(1u << l)) : 0u;
-  co_for<0, NC>([&](auto jc) {
+  for (int k = 0; k < NC; ++k) A[k] = a ? onehot[k] : H[k];
+  A[NC] = a ? 0.0 : rhs;
+  double piv = co_bcast64<0>(A[0]);
+  co_for<0, NC - 1>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    const double rp = mk_rcp(co_bcast<j>(A[j]));
-    const double f = ((w >> j) & 1u) ? A[j] * rp : 0.0;
-    F.f[j] = f;
-    co_for<j + 1, NC>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      A[k] = fma(-f, co_bcast<j>(A[k]), A[k]);
-    });
+    const double nf = fma(-A[j], mk_rcp(piv), onehot[j]);
+    F.nf[j] = nf;
+    co_pivot<j, j + 1, NC - j>(A, nf, piv);
   });
+  {
+    const double nf = fma(-A[NC - 1], mk_rcp(piv), onehot[NC - 1]);
+    F.nf[NC - 1] = nf;
+    co_elim<NC - 1, NC, NC + 1>(A, nf);
+  }
   double d = 0.0;
 #pragma unroll
   for (int k = 0; k < NC; ++k) d = fma(onehot[k], A[k], d);
   F.invd = valid ? mk_rcp(d) : 0.0;
+  return A[NC] * F.invd;
 }
 
 template <int NC>
 MK_CO double co_apply(const CoFactor<NC>& F, double rhs) {
-  co_for<0, NC>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    rhs = fma(-F.f[j], co_bcast<j>(rhs), rhs);
-  });
+  co_replay<0, NC>(rhs, F.nf);
   return rhs * F.invd;
 }
 
@@ -290,10 +565,7 @@ MK_CO double co_apply(const CoFactor<NC>& F, double rhs) {
 template <int NC>
 MK_CO double co_symv(const double (&H)[NC], double x) {
   double y = 0.0;
-  co_for<0, NC>([&](auto kc) {
-    constexpr int k = decltype(kc)::value;
-    y = fma(H[k], co_bcast<k>(x), y);
-  });
+  co_dot<NC>(y, x, H);
   return y;
 }
 
@@ -302,7 +574,7 @@ MK_CO double co_symv(const double (&H)[NC], double x) {
 // from the S-pair phase 1 ends in -- with one variable per lane.  The active set and its sides
 // are 16-bit masks, the same in every lane of the row.  hdiag = H_ll.
 // Returns 0 ok / 1 iteration limit / 2 infeasible.
-template <int NC, bool REFINE>
+template <int NC>
 MK_CO int co_box_qp(const double (&H)[NC], double hdiag, const double (&onehot)[NC], double c, double lo, double hi,
                     bool valid, double& x, uint32_t& act_io, uint32_t& upper_io, bool warm) {
   constexpr double kTol = 1e-14;
@@ -329,16 +601,12 @@ MK_CO int co_box_qp(const double (&H)[NC], double hdiag, const double (&onehot)[
     if (!settled) {
       const bool a = (act & bit) != 0u;
       const double xa = a ? ((upper & bit) ? hi : lo) : 0.0;
-      const double rhs = -c - co_symv<NC>(H, xa);
-      co_factor<NC>(H, onehot, act, valid, F);
-      double xf = co_apply<NC>(F, rhs);
-      if (REFINE) {
-        // one step of iterative refinement on the free block
-        const double res = rhs - co_symv<NC>(H, a ? 0.0 : xf);
-        xf += co_apply<NC>(F, res);
-      }
+      double rhs = -c;
+      co_dot<NC>(rhs, -xa, H);
+      const double xf = co_factor_solve<NC>(H, onehot, act, valid, rhs, F);
       x = a ? xa : xf;
-      const double g = c + co_symv<NC>(H, x);
+      double g = c;
+      co_dot<NC>(g, x, H);
       const double ui = (upper & bit) ? -g : g;
       const uint32_t drop = co_ballot(valid && a && ui < 0.0);
       const bool over = !a && x - hi > kTol, under = !a && lo - x > kTol;
@@ -364,9 +632,11 @@ MK_CO int co_box_qp(const double (&H)[NC], double hdiag, const double (&onehot)[
     if (!done && p < 0) {
       const bool fr = valid && (act & bit) == 0u;
       const double vh = x - hi, vl = lo - x;
-      double worst;
-      int who;
-      co_argmax(fr ? fmax(vh, vl) : -INFINITY, worst, who);
+      const double viol = fr ? fmax(vh, vl) : -INFINITY;
+      double worst = 0.0;
+      int who = -1;
+      // (the arg-max only when some bound is violated at all: rarely, after phase 1)
+      if (co_ballot(viol > kTol) != 0u) co_argmax(viol, worst, who);
       if (worst > kTol) {
         p = who;
         const bool up = co_pick(vh >= vl ? 1.0 : 0.0, p) != 0.0;
@@ -380,7 +650,8 @@ MK_CO int co_box_qp(const double (&H)[NC], double hdiag, const double (&onehot)[
     if (mk_wave_none(!done)) break;
     if (!have_u) {   // wave-uniform
       have_u = true;
-      const double g = c + co_symv<NC>(H, x);
+      double g = c;
+      co_dot<NC>(g, x, H);
       const double ui = (upper & bit) ? -g : g;
       u = (valid && (act & bit) != 0u && ui > 0.0) ? ui : 0.0;
     }
@@ -412,7 +683,7 @@ MK_CO int co_box_qp(const double (&H)[NC], double hdiag, const double (&onehot)[
       } else if (kb >= 0) {
         act &= ~(1u << kb);
       }
-      co_factor<NC>(H, onehot, act, valid, F);
+      (void)co_factor_solve<NC>(H, onehot, act, valid, 0.0, F);
     }
   }
   if (!done) status = 1;
@@ -434,17 +705,14 @@ struct CoProblem {
 
 // One solve_ik for the row's problem from its chain kinematics (mink/solve_ik.py:68-105): QP
 // assembly (H row, c, bounds), the box QP on the chain dofs and the clamps of the other dofs.
-// Jc is consumed.  Returns the status; dq of the chain dof in x, of the lane's first other dof
+// Jc is this lane's Jacobian column, e the frame-task error, (Ji, Qm) its Jacobian blocks.  Returns the status; dq of the chain dof in x, of the lane's first other dof
 // in xd; dofs d = l + 16 r (r >= 1) outside the chain are handled through `rest`, called once
 // per such dof as rest(dof constants, dq).
-template <int NC, bool REFINE, class RestQ, class RestOut>
+template <int NC, class RestQ, class RestOut>
 MK_CO int co_solve(const MkFusedDesc* __restrict__ D, const CoLane<NC>& C, CoProblem<NC>& P, double (&Jc)[6], Twist e,
-                   double dt, double damping, bool warm, double& x, double& xd, RestQ&& rest_q, RestOut&& rest_out) {
-  M3 Ji, Qm;
-  co_ljacinv_parts(e, Ji, Qm);
-  double cost[6];
-#pragma unroll
-  for (int r = 0; r < 6; ++r) cost[r] = D->cost[r];
+                   const M3& Ji, const M3& Qm, double dt, double damping, bool warm, double& x, double& xd,
+                   RestQ&& rest_q, RestOut&& rest_out) {
+  const double (&cost)[6] = C.cost;
   // Jw = diag(cost) (-jlog) J_b for this lane's column (frame_task.py:146, task.py:125-127)
   double Jw[6];
   {
@@ -454,19 +722,17 @@ MK_CO int co_solve(const MkFusedDesc* __restrict__ D, const CoLane<NC>& C, CoPro
     Jw[0] = -cost[0] * tl.x; Jw[1] = -cost[1] * tl.y; Jw[2] = -cost[2] * tl.z;
     Jw[3] = -cost[3] * ta.x; Jw[4] = -cost[4] * ta.y; Jw[5] = -cost[5] * ta.z;
   }
-  const double g = D->gain;
+  const double g = C.gain;
   const double ew[6] = {cost[0] * (-g * e.v.x), cost[1] * (-g * e.v.y), cost[2] * (-g * e.v.z),
                         cost[3] * (-g * e.w.x), cost[4] * (-g * e.w.y), cost[5] * (-g * e.w.z)};
-  const double diag = damping + D->lm * (ew[0] * ew[0] + ew[1] * ew[1] + ew[2] * ew[2] + ew[3] * ew[3] +
+  const double diag = damping + C.lm * (ew[0] * ew[0] + ew[1] * ew[1] + ew[2] * ew[2] + ew[3] * ew[3] +
                                          ew[4] * ew[4] + ew[5] * ew[5]);
   // row l of H = Jw'Jw + (diag + W) I
   double H[NC];
   co_for<0, NC>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    double s = 0.0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) s = fma(Jw[r], co_bcast<k>(Jw[r]), s);
-    H[k] = fma(C.onehot[k], diag + C.sd.W, s);
+    H[k] = C.onehot[k] * (diag + C.sd.W);
+    co_gram<k>(H[k], Jw);
   });
   double hdiag = diag + C.sd.W, s = 0.0;
 #pragma unroll
@@ -478,18 +744,18 @@ MK_CO int co_solve(const MkFusedDesc* __restrict__ D, const CoLane<NC>& C, CoPro
   const double vb = dt * C.sd.vmax;
   const double hi = fmin(C.sd.gain * (C.sd.upper - P.qc), vb);
   const double lo = fmax(-(C.sd.gain * (P.qc - C.sd.lower)), -vb);
-  int status = co_box_qp<NC, REFINE>(H, hdiag, C.onehot, c, lo, hi, C.valid, x, P.act, P.upper, warm);
+  int status = co_box_qp<NC>(H, hdiag, C.onehot, c, lo, hi, C.valid, x, P.act, P.upper, warm);
   // non-finite chain q or target (the error, hence every entry of c, is NaN), a non-finite
   // coordinate outside the chain, or damping = 0 with a vanishing Levenberg-Marquardt term on a
   // dof without task cost (singular P, which the reference's QP backend rejects,
   // mink/solve_ik.py:101-103)
   const bool nonfinite = co_ballot(C.valid && !(fabs(diag + c) < INFINITY)) != 0u;
-  if (P.input_bad || nonfinite || (D->needs_diag && !(diag > 0.0))) {
+  if (P.input_bad || nonfinite || (C.needs_diag && !(diag > 0.0))) {
     status = 3;
     x = 0.0;
   }
   // ---- dofs outside the chain: diagonal Hessian, box limits -> clamp ----
-  const int nd = D->nd;
+  const int nd = C.nd;
   bool infeasible = false;
   auto clamp_dof = [&](const MkDofC& dc, double qi) -> double {
     const double vbd = dt * dc.vmax;
@@ -550,7 +816,7 @@ MK_CO void co_load_problem(const MkFusedDesc* __restrict__ D, const CoLane<NC>& 
 }
 
 // mk_solve_ik_batch on the cooperative form: one solve_ik for problem g (one row of lanes).
-template <int NC, bool REFINE>
+template <int NC>
 MK_CO void coop_step_body(const MkFusedDesc* __restrict__ D, const double* __restrict__ q,
                           const double* __restrict__ targets, int target_stride, double dt, double damping, int B,
                           double* __restrict__ v_out, int32_t* __restrict__ status_out, long g) {
@@ -570,11 +836,12 @@ MK_CO void coop_step_body(const MkFusedDesc* __restrict__ D, const double* __res
   double Jc[6];
   CoPose W;
   co_chain<NC>(C, P.qc, Jc, W);
-  const Twist e = frame_error(W.q, W.t, q2m(W.q), Qt, pt);
+  M3 Ji, Qm;
+  const Twist e = co_frame_error_jlog(W.q, W.t, Qt, pt, Ji, Qm);
   double x, xd;
   double* vrow = v_out + pb * nv;
-  const int status = co_solve<NC, REFINE>(
-      D, C, P, Jc, e, dt, damping, false, x, xd, [&](const MkDofC& dc) { return qrow[dc.qadr]; },
+  const int status = co_solve<NC>(
+      D, C, P, Jc, e, Ji, Qm, dt, damping, false, x, xd, [&](const MkDofC& dc) { return qrow[dc.qadr]; },
       [&](const MkDofC& dc, double, double dq) { if (live) vrow[dc.dof] = dq * inv_dt; });
   if (live) {
     if (C.dof >= 0) vrow[C.dof] = x * inv_dt;
@@ -587,17 +854,17 @@ MK_CO void coop_step_body(const MkFusedDesc* __restrict__ D, const double* __res
 
 // mk_solve_ik_iterate_batch on the cooperative form: the callers' loop
 // (interactive_scripts/teleop_mouse.py:105-121) -- up to max_iters x (solve_ik ->
-// integrate_inplace -> frame-task error -> exit test) -- for problem g, with the
-// configuration in registers.
-template <int NC, bool REFINE>
+// integrate_inplace -> frame-task error -> exit test) -- for problem pb, with the
+// configuration in registers.  A row with live == false computes and stores nothing new.
+// it0 / status0: the loop resumes after it0 solves already executed (by the lane-per-problem
+// kernel, see coop_resume_kernel) with their worst status.
+template <int NC>
 MK_CO void coop_iterate_body(const MkFusedDesc* __restrict__ D, double* __restrict__ q,
-                             const double* __restrict__ targets, int target_stride, double dt, double damping, int B,
+                             const double* __restrict__ targets, int target_stride, double dt, double damping,
                              int max_iters, double pos_tol, double ori_tol, double* __restrict__ v_out,
                              int32_t* __restrict__ iters_out, double* __restrict__ err_out,
-                             int32_t* __restrict__ status_out, long g) {
+                             int32_t* __restrict__ status_out, long pb, bool live, int it0, int status0) {
   const int l = co_lane();
-  const bool live = g < B;
-  const long pb = live ? g : B - 1;
   const int nq = D->nq, nv = D->nv;
   const double inv_dt = 1.0 / dt;
   CoLane<NC> C;
@@ -610,23 +877,26 @@ MK_CO void coop_iterate_body(const MkFusedDesc* __restrict__ D, double* __restri
   const V3 pt = v3(tg[4], tg[5], tg[6]);
   double* vrow = (live && v_out) ? v_out + pb * nv : nullptr;
   Twist e = Twist{v3(0, 0, 0), v3(0, 0, 0)};
-  int status = 0, iters = 0;
+  int status = status0, iters = it0;
   bool done = false;
   double vx = 0.0, vd = 0.0;
-  for (int it = 0; it <= max_iters; ++it) {
+  const double pos_tol2 = pos_tol >= 0.0 ? pos_tol * pos_tol : -1.0, ori_tol2 = ori_tol >= 0.0 ? ori_tol * ori_tol : -1.0;
+  for (int it = it0; it <= max_iters; ++it) {
     if (!done) {
       double Jc[6];
       CoPose W;
       co_chain<NC>(C, P.qc, Jc, W);
-      e = frame_error(W.q, W.t, q2m(W.q), Qt, pt);
+      M3 Ji, Qm;
+      e = co_frame_error_jlog(W.q, W.t, Qt, pt, Ji, Qm);
       // exit test of the callers' loop, on the configuration reached by the previous solve
-      const bool conv = it > 0 && sqrt(dot(e.v, e.v)) <= pos_tol && sqrt(dot(e.w, e.w)) <= ori_tol;
+      // (|e| <= tol as |e|^2 <= tol^2; a negative tolerance never passes)
+      const bool conv = it > 0 && dot(e.v, e.v) <= pos_tol2 && dot(e.w, e.w) <= ori_tol2;
       if (conv || it == max_iters) {
         done = true;
       } else {
         double x, xd;
-        const int st = co_solve<NC, REFINE>(
-            D, C, P, Jc, e, dt, damping, it > 0, x, xd, [&](const MkDofC& dc) { return qrow[dc.qadr]; },
+        const int st = co_solve<NC>(
+            D, C, P, Jc, e, Ji, Qm, dt, damping, it > it0, x, xd, [&](const MkDofC& dc) { return qrow[dc.qadr]; },
             [&](const MkDofC& dc, double qi, double dq) {
               const double vi = dq * inv_dt;
               if (live) qrow[dc.qadr] = qi + dt * vi;
@@ -643,12 +913,15 @@ MK_CO void coop_iterate_body(const MkFusedDesc* __restrict__ D, double* __restri
     if (mk_wave_none(!done)) break;
   }
   if (live) {
-    if (C.dof >= 0) qrow[C.qadr] = P.qc;
-    if (P.has_dd) qrow[P.dd.qadr] = P.qd;
-    if (iters > 0) co_free_renorm(D, qrow);
-    if (vrow) {
+    const bool solved = iters > it0;   // otherwise q and v are as they came
+    if (solved) {
+      if (C.dof >= 0) qrow[C.qadr] = P.qc;
+      if (P.has_dd) qrow[P.dd.qadr] = P.qd;
+      co_free_renorm(D, qrow);
+    }
+    if (vrow && (solved || it0 == 0)) {
       if (C.dof >= 0) vrow[C.dof] = vx;
-      if (iters > 0) {
+      if (solved) {
         if (P.has_dd) vrow[P.dd.dof] = vd;
         for (int f = 0; f < D->nfree; ++f)
           if (l < 6) vrow[D->free_dofadr[f] + l] = 0.0;
@@ -666,24 +939,62 @@ MK_CO void coop_iterate_body(const MkFusedDesc* __restrict__ D, double* __restri
 }
 
 #if !defined(MK_COOP_NO_KERNELS)
-template <int NC, bool REFINE>
+template <int NC>
 __global__ __launch_bounds__(64) void coop_step_kernel(const MkFusedDesc* __restrict__ D, const double* __restrict__ q,
                                                        const double* __restrict__ targets, int target_stride, double dt,
                                                        double damping, int B, double* __restrict__ v_out,
                                                        int32_t* __restrict__ status_out) {
-  coop_step_body<NC, REFINE>(D, q, targets, target_stride, dt, damping, B, v_out, status_out,
-                             (long)blockIdx.x * 4 + (threadIdx.x >> 4));
+  coop_step_body<NC>(D, q, targets, target_stride, dt, damping, B, v_out, status_out,
+                     (long)blockIdx.x * 4 + (threadIdx.x >> 4));
 }
 
-template <int NC, bool REFINE>
+template <int NC>
 __global__ __launch_bounds__(64) void coop_iterate_kernel(const MkFusedDesc* __restrict__ D, double* __restrict__ q,
                                                           const double* __restrict__ targets, int target_stride,
                                                           double dt, double damping, int B, int max_iters, double pos_tol,
                                                           double ori_tol, double* __restrict__ v_out,
                                                           int32_t* __restrict__ iters_out, double* __restrict__ err_out,
                                                           int32_t* __restrict__ status_out) {
-  coop_iterate_body<NC, REFINE>(D, q, targets, target_stride, dt, damping, B, max_iters, pos_tol, ori_tol, v_out,
-                                iters_out, err_out, status_out, (long)blockIdx.x * 4 + (threadIdx.x >> 4));
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 4);
+  const bool live = g < B;   // a row without a problem repeats the last one and stores nothing
+  coop_iterate_body<NC>(D, q, targets, target_stride, dt, damping, max_iters, pos_tol, ori_tol, v_out, iters_out, err_out,
+                        status_out, live ? g : B - 1, live, 0, 0);
+}
+
+// Second phase of the callers' loop on batches that fill the machine's lanes once: the
+// lane-per-problem kernel (fused_iterate_kernel, mk_fused.hip) stops a wave when only a few of
+// its 64 problems are still in the loop and marks them in `iters` (MK_ITER_CONT_BIT next to the
+// solves executed so far); those stragglers -- a handful per wave, but they would hold the launch
+// for their remaining sequential solves at 64 problems per wave -- finish here at 16 lanes per
+// problem.  Wave w takes the 64-entry chunks w, w + gridDim.x, ... of the batch: one load of the
+// marks, a ballot, and the marked problems of the chunk four at a time (one per row).
+template <int NC>
+__global__ __launch_bounds__(64) void coop_resume_kernel(const MkFusedDesc* __restrict__ D, double* __restrict__ q,
+                                                         const double* __restrict__ targets, int target_stride,
+                                                         double dt, double damping, int B, int max_iters, double pos_tol,
+                                                         double ori_tol, double* __restrict__ v_out,
+                                                         int32_t* __restrict__ iters_out, double* __restrict__ err_out,
+                                                         int32_t* __restrict__ status_out) {
+  const int row = threadIdx.x >> 4;
+  const int nchunks = (B + 63) / 64;
+  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const long idx = (long)ch * 64 + threadIdx.x;
+    const int32_t mark = idx < B ? iters_out[idx] : 0;
+    uint64_t mask = __ballot((mark & MK_ITER_CONT_BIT) != 0);
+    while (mask != 0ull) {   // wave-uniform
+      // row r takes the r-th marked problem still waiting, if there is one
+      uint64_t m = mask;
+      for (int k = 0; k < row; ++k) m &= m - 1ull;
+      const bool has = m != 0ull;
+      if (has) {
+        const long pb = (long)ch * 64 + (__ffsll((unsigned long long)m) - 1);
+        const int32_t it0 = iters_out[pb] & ~MK_ITER_CONT_BIT;
+        coop_iterate_body<NC>(D, q, targets, target_stride, dt, damping, max_iters, pos_tol, ori_tol, v_out, iters_out,
+                              err_out, status_out, pb, true, it0, status_out[pb]);
+      }
+      for (int k = 0; k < 4; ++k) mask &= mask - 1ull;
+    }
+  }
 }
 #endif
 
@@ -691,45 +1002,55 @@ __global__ __launch_bounds__(64) void coop_iterate_kernel(const MkFusedDesc* __r
 
 #if !defined(MK_COOP_NO_KERNELS)
 // ---- host-side launchers (called from mk_api.hip) ----
-#define MK_COOP_CASES(M) M(4) M(6) M(7) M(8) M(10) M(12)
-
-hipError_t mk_coop_launch_step(int nc, bool refine, const MkFusedDesc* d_desc, const double* q, const double* targets,
+hipError_t mk_coop_launch_step(int nc, const MkFusedDesc* d_desc, const double* q, const double* targets,
                                int target_stride, double dt, double damping, int B, double* v, int32_t* status,
                                hipStream_t stream) {
   const int blocks = (B + 3) / 4;
   switch (nc) {
-#define MK_CASE(N)                                                                                                    \
-  case N:                                                                                                             \
-    if (refine)                                                                                                       \
-      hipLaunchKernelGGL((coop_step_kernel<N, true>), dim3(blocks), dim3(64), 0, stream, d_desc, q, targets,          \
-                         target_stride, dt, damping, B, v, status);                                                   \
-    else                                                                                                              \
-      hipLaunchKernelGGL((coop_step_kernel<N, false>), dim3(blocks), dim3(64), 0, stream, d_desc, q, targets,         \
-                         target_stride, dt, damping, B, v, status);                                                   \
+#define MK_CASE(N)                                                                                                      \
+  case N:                                                                                                               \
+    hipLaunchKernelGGL(coop_step_kernel<N>, dim3(blocks), dim3(64), 0, stream, d_desc, q, targets, target_stride, dt,   \
+                       damping, B, v, status);                                                                          \
     break;
-    MK_COOP_CASES(MK_CASE)
+    MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
 #undef MK_CASE
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-hipError_t mk_coop_launch_iterate(int nc, bool refine, const MkFusedDesc* d_desc, double* q, const double* targets,
+hipError_t mk_coop_launch_iterate(int nc, const MkFusedDesc* d_desc, double* q, const double* targets,
                                   int target_stride, double dt, double damping, int B, int max_iters, double pos_tol,
                                   double ori_tol, double* v, int32_t* iters, double* err, int32_t* status,
                                   hipStream_t stream) {
   const int blocks = (B + 3) / 4;
   switch (nc) {
-#define MK_CASE(N)                                                                                                    \
-  case N:                                                                                                             \
-    if (refine)                                                                                                       \
-      hipLaunchKernelGGL((coop_iterate_kernel<N, true>), dim3(blocks), dim3(64), 0, stream, d_desc, q, targets,       \
-                         target_stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status);          \
-    else                                                                                                              \
-      hipLaunchKernelGGL((coop_iterate_kernel<N, false>), dim3(blocks), dim3(64), 0, stream, d_desc, q, targets,      \
-                         target_stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status);          \
+#define MK_CASE(N)                                                                                                      \
+  case N:                                                                                                               \
+    hipLaunchKernelGGL(coop_iterate_kernel<N>, dim3(blocks), dim3(64), 0, stream, d_desc, q, targets, target_stride,    \
+                       dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status);                             \
     break;
-    MK_COOP_CASES(MK_CASE)
+    MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
+#undef MK_CASE
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// The problems that a lane-per-problem launch marked with MK_ITER_CONT_BIT in `iters`.
+hipError_t mk_coop_launch_resume(int nc, const MkFusedDesc* d_desc, double* q, const double* targets, int target_stride,
+                                 double dt, double damping, int B, int max_iters, double pos_tol, double ori_tol,
+                                 double* v, int32_t* iters, double* err, int32_t* status, int max_blocks,
+                                 hipStream_t stream) {
+  const int nchunks = (B + 63) / 64;
+  const int blocks = nchunks < max_blocks ? nchunks : max_blocks;
+  switch (nc) {
+#define MK_CASE(N)                                                                                                      \
+  case N:                                                                                                               \
+    hipLaunchKernelGGL(coop_resume_kernel<N>, dim3(blocks), dim3(64), 0, stream, d_desc, q, targets, target_stride,     \
+                       dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status);                             \
+    break;
+    MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
 #undef MK_CASE
     default: return hipErrorInvalidValue;
   }

@@ -107,6 +107,10 @@ constexpr int MK_MAX_CGEOM = 24;
 constexpr int MK_MAX_CPAIR = 40;
 enum { MK_CB_WORLD = 0, MK_CB_TIP = 1, MK_CB_FREE = 2 };   // TIP: carried by a joint frame of the chain
 constexpr int32_t MK_STATUS_PENDING = 1 << 30;   // in a status entry: the general kernel still has to solve it
+// In an entry of the iterated entry's `iters` array between the two launches of a loop with an
+// exit test: the lane-per-problem kernel left this problem's loop after the count in the low bits;
+// the cooperative kernel takes it on from there.
+constexpr int32_t MK_ITER_CONT_BIT = 1 << 29;
 
 struct MkCollSeg {        // like MkSegC: fixed transform, then motion about / along z
   double pq[4], pp[3];

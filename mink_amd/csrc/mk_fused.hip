@@ -1487,7 +1487,12 @@ __global__ MK_KERNEL_ATTR void fused_step_ext_kernel(const MkFusedDesc* __restri
   tile_copy<false>(tile, stride, v_out + base * nv, rows, nv);
 }
 
-template <int NC>
+// HANDOFF: a wave whose problems have all but `handoff_live` of them left the loop stops there and
+// marks the rest (MK_ITER_CONT_BIT in iters_out, which must be given): with the exit test the
+// problems of a wave finish at different iterations, and the last few would hold the launch for
+// their remaining sequential solves; the cooperative kernel (coop_resume_kernel, mk_coop.hip)
+// finishes them at 16 lanes per problem.
+template <int NC, bool HANDOFF = false>
 __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restrict__ D_arg,
                                                            double* __restrict__ q,
                                                            const double* __restrict__ targets, int target_stride,
@@ -1495,7 +1500,7 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
                                                            double pos_tol, double ori_tol,
                                                            double* __restrict__ v_out, int32_t* __restrict__ iters_out,
                                                            double* __restrict__ err_out,
-                                                           int32_t* __restrict__ status_out) {
+                                                           int32_t* __restrict__ status_out, int handoff_live = 0) {
   const MkFusedDesc* D = D_arg;
   extern __shared__ double tile[];
   const int nq = D->nq, nv = D->nv;
@@ -1524,7 +1529,7 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
   const bool input_bad = rest_nonfinite(D, row);
   Twist e = Twist{v3(0, 0, 0), v3(0, 0, 0)};
   int status = 0, iters = 0;
-  bool done = false;
+  bool done = false, handed = false;
   uint32_t act = 0u, upper = 0u;  // active bounds of the previous step: warm start of the next
   double* vrow = (valid && v_out) ? v_out + pb * nv : nullptr;
   for (int it = 0; it <= max_iters; ++it) {
@@ -1536,8 +1541,18 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
       // exit test of the callers' loop, evaluated on the configuration reached by
       // the previous solve (interactive_scripts/teleop_mouse.py:117-121)
       const bool conv = it > 0 && sqrt(dot(e.v, e.v)) <= pos_tol && sqrt(dot(e.w, e.w)) <= ori_tol;
+      bool hand = false;
+      if constexpr (HANDOFF) {
+        // the lanes of this branch that are about to solve: few enough (and not before the first
+        // solve, whose cold start the lane form amortises best), they go to the cooperative kernel
+        const bool go = !(conv || it == max_iters);
+        hand = go && it > 0 && __popcll(__ballot(go)) <= handoff_live;
+      }
       if (conv || it == max_iters) {
         done = true;
+      } else if (HANDOFF && hand) {
+        done = true;
+        handed = true;
       } else {
 #if defined(MK_ABLATE) && MK_ABLATE == 1
         // tuning build only: forward kinematics + error, no QP build / solve
@@ -1569,7 +1584,7 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
   }
   if (valid) {
     status_out[pb] = status;
-    if (iters_out) iters_out[pb] = iters;
+    if (iters_out) iters_out[pb] = (HANDOFF && handed) ? (iters | MK_ITER_CONT_BIT) : iters;
     if (err_out) {
       double* eo = err_out + pb * 6;
       eo[0] = e.v.x; eo[1] = e.v.y; eo[2] = e.v.z; eo[3] = e.w.x; eo[4] = e.w.y; eo[5] = e.w.z;
@@ -1867,12 +1882,18 @@ template <int NC>
 static hipError_t launch_iterate(const MkFusedDesc* d_desc, int nq, double* q, const double* targets,
                                  int target_stride, double dt, double damping, int B, int max_iters, double pos_tol,
                                  double ori_tol, double* v, int32_t* iters, double* err, int32_t* status,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, int handoff_live) {
   const int blocks = (B + 63) / 64;
   const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
-  if (hipError_t e = allow_lds<fused_iterate_kernel<NC>>(lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL(fused_iterate_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
-                     target_stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status);
+  if (handoff_live > 0) {
+    if (hipError_t e = allow_lds<fused_iterate_kernel<NC, true>>(lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL((fused_iterate_kernel<NC, true>), dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
+                       target_stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status, handoff_live);
+    return hipGetLastError();
+  }
+  if (hipError_t e = allow_lds<fused_iterate_kernel<NC, false>>(lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((fused_iterate_kernel<NC, false>), dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
+                     target_stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status, 0);
   return hipGetLastError();
 }
 
@@ -1976,10 +1997,14 @@ hipError_t mk_fused_launch_rows(int nc, const MkFusedDesc* d_desc, const MkFused
   }
 }
 
+// handoff_live > 0 (and an exit test, and `iters` given): the block-per-64 kernel may leave up to
+// that many problems per wave marked MK_ITER_CONT_BIT for mk_coop_launch_resume; *handed tells
+// whether this launch was of that kind.
 hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, double* q, const double* targets,
                                    int target_stride, double dt, double damping, int B, int max_iters,
                                    double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
-                                   int32_t* status, hipStream_t stream) {
+                                   int32_t* status, hipStream_t stream, int handoff_live, bool* handed) {
+  if (handed) *handed = false;
   // With an exit test and more problems than twice the lanes of the machine, lanes stream
   // through the problems of a chunk (one persistent wave per slot); otherwise one block of 64
   // problems per wave with coalesced tile copies.
@@ -2002,11 +2027,13 @@ hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, do
       default: return hipErrorInvalidValue;
     }
   }
+  if (!(handoff_live > 0 && iters != nullptr && pos_tol >= 0.0 && ori_tol >= 0.0 && max_iters > 2)) handoff_live = 0;
+  if (handed) *handed = handoff_live > 0;
   switch (nc) {
 #define MK_CASE(N)                                                                                         \
   case N:                                                                                                  \
     return launch_iterate<N>(d_desc, nq, q, targets, target_stride, dt, damping, B, max_iters, pos_tol,   \
-                             ori_tol, v, iters, err, status, stream);
+                             ori_tol, v, iters, err, status, stream, handoff_live);
     MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
 #undef MK_CASE
     default: return hipErrorInvalidValue;

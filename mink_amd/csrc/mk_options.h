@@ -13,7 +13,7 @@ enum MkOption {
   MK_OPT_STREAM_REFILL,    // lanes that must wait before the streaming kernels hand out new problems
   MK_OPT_COOP,             // -1: the cooperative (16 lanes per problem) kernels by batch size; 0: never; 1: always
   MK_OPT_COOP_MAX_BATCH,   // largest batch the cooperative kernels take when MK_OPT_COOP is -1
-  MK_OPT_COOP_REFINE,      // 1: the cooperative solver refines each solve once (iterative refinement)
+  MK_OPT_HANDOFF,          // loops with an exit test on the block-per-64 kernel: -1 a wave hands its last 4 live problems to the cooperative kernel; 0 never; n > 0: its last n
   MK_OPT_COUNT
 };
 

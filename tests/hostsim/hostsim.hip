@@ -262,8 +262,8 @@ int run_coop_step(const MkFusedDesc& D, const double* q, const double* targets, 
                   int B, double* v, int32_t* status, int refine) {
   for (long g = 0; g < B; ++g)
     cosim::run_row([&] {
-      if (refine) coop_step_body<NC, true>(&D, q, targets, stride, dt, damping, B, v, status, g);
-      else coop_step_body<NC, false>(&D, q, targets, stride, dt, damping, B, v, status, g);
+      (void)refine;
+      coop_step_body<NC>(&D, q, targets, stride, dt, damping, B, v, status, g);
     });
   return 0;
 }
@@ -274,12 +274,9 @@ int run_coop_iterate(const MkFusedDesc& D, double* q, const double* targets, int
                      int32_t* status, int refine) {
   for (long g = 0; g < B; ++g)
     cosim::run_row([&] {
-      if (refine)
-        coop_iterate_body<NC, true>(&D, q, targets, stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err,
-                                    status, g);
-      else
-        coop_iterate_body<NC, false>(&D, q, targets, stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err,
-                                     status, g);
+      (void)refine;
+      coop_iterate_body<NC>(&D, q, targets, stride, dt, damping, max_iters, pos_tol, ori_tol, v, iters, err, status, g,
+                            true, 0, 0);
     });
   return 0;
 }

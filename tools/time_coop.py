@@ -51,21 +51,21 @@ for B in (1, 64, 1024, 4096, 8192, 16384, 32768, 65536):
     print(f"  B={B:6d}  lane {row[0]:8.2f}  coop {row[1]:8.2f}")
 
 print("callers' loop (<= 20 iterations, 1e-4 exit), near targets: us per launch, mean solves")
-for B in (1, 64, 1024, 4096, 16384, 65536):
+for B in (1, 64, 1024, 4096, 16384, 32768, 65536):
     t = near[:B].contiguous()
     out = dict(iters=torch.empty(B, dtype=torch.int32, device=dev), err=torch.empty((B, 6), dtype=torch.float64, device=dev),
                status=torch.empty(B, dtype=torch.int32, device=dev))
     qs = [q0[:B].clone() for _ in range(60)]
     row = []
-    for form in (0, 1):
+    for form in (0, 1, -1):   # lane kernels alone, cooperative kernels alone, the library's choice
         with L.options(coop=form):
             for k, qq in enumerate(qs):
                 qq.copy_(q0[:B])
             it = iter(qs)
             us = ev_time(lambda: pn.iterate_(next(it), t, W.DT, W.DAMPING, 20, 1e-4, 1e-4, out=out), n=50, warm=5)
             row.append((us, float(out["iters"].double().mean()), int(out["iters"].max())))
-    print(f"  B={B:6d}  lane {row[0][0]:8.2f} (mean {row[0][1]:.2f} max {row[0][2]})  coop {row[1][0]:8.2f} (mean {row[1][1]:.2f})"
-          f"  -> coop {B * row[1][1] / row[1][0]:.1f} M solves/s")
+    print(f"  B={B:6d}  lane {row[0][0]:8.2f} (mean {row[0][1]:.2f} max {row[0][2]})  coop {row[1][0]:8.2f}"
+          f"  default {row[2][0]:8.2f} (mean {row[2][1]:.2f})  -> default {B * row[2][1] / row[2][0]:.1f} M solves/s")
 
 # wall time per call at B = 1 (launch + sync), as the 200 Hz teleop loop sees it
 q1, t1 = q0[:1].clone(), near[:1].contiguous()
