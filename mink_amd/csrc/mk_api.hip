@@ -50,6 +50,15 @@ hipError_t mk_coop_launch_iterate(int nc, const MkFusedDesc* d_desc, double* q, 
                                   int target_stride, double dt, double damping, int B, int max_iters, double pos_tol,
                                   double ori_tol, double* v, int32_t* iters, double* err, int32_t* status,
                                   hipStream_t stream);
+hipError_t mk_coop_launch_move_to(int nc, const MkFusedDesc* d_desc, double* q, const double* goals, double dt,
+                                  double damping, int B, int max_steps, int max_iters, double pos_tol, double ori_tol,
+                                  double wp_pos_thr, double wp_pos_step, double wp_rot_thr, int32_t* steps,
+                                  int32_t* reached, int32_t* solves, int32_t* status, hipStream_t stream);
+hipError_t mk_coop_launch_move_to_resume(int nc, const MkFusedDesc* d_desc, double* q, const double* goals, double dt,
+                                         double damping, int B, int max_steps, int max_iters, double pos_tol,
+                                         double ori_tol, double wp_pos_thr, double wp_pos_step, double wp_rot_thr,
+                                         int32_t* steps, int32_t* reached, int32_t* solves, int32_t* status,
+                                         int max_blocks, hipStream_t stream);
 hipError_t mk_coop_launch_resume(int nc, const MkFusedDesc* d_desc, double* q, const double* targets, int target_stride,
                                  double dt, double damping, int B, int max_iters, double pos_tol, double ori_tol,
                                  double* v, int32_t* iters, double* err, int32_t* status, int max_blocks,
@@ -75,7 +84,7 @@ hipError_t mk_fused_launch_move_to(int nc, const MkFusedDesc* d_desc, int nq, do
                                    double dt, double damping, int B, int max_steps, int max_iters, double pos_tol,
                                    double ori_tol, double wp_pos_thr, double wp_pos_step, double wp_rot_thr,
                                    int32_t* steps, int32_t* reached, int32_t* solves, int32_t* status,
-                                   hipStream_t stream);
+                                   hipStream_t stream, int handoff_live, bool* handed);
 
 // ---- implemented in mk_lie.hip ----
 int mk_lie_shape(int op, int* wa, int* wb, int* wo);
@@ -1177,6 +1186,15 @@ static bool use_coop(const mk_problem* p, int B) {
   return mode > 0 || B <= mk_opt(MK_OPT_COOP_MAX_BATCH);
 }
 
+// Live problems per wave at which the lane-per-problem kernels pass them on to the cooperative
+// kernels (0: never; posture tasks with a Levenberg-Marquardt term stay with the lane form).
+static long handoff_threshold(const mk_problem* p) {
+  long handoff = mk_opt(MK_OPT_HANDOFF);
+  if (handoff < 0) handoff = 4;
+  if (p->h_fused.any_posture_lm || mk_opt(MK_OPT_COOP) == 0) handoff = 0;
+  return handoff;
+}
+
 int mk_set_option(const char* name, int64_t value) {
   if (!name) return fail(MK_ERR_INVALID, "null option name");
   for (int i = 0; i < MK_OPT_COUNT; ++i)
@@ -1327,9 +1345,7 @@ int mk_solve_ik_iterate_batch(const mk_problem* p, double* d_q, const double* d_
   // With an exit test the lane-per-problem kernel hands the last few live problems of each wave to
   // the cooperative kernel (second launch below); not for posture tasks with a Levenberg-Marquardt
   // term, which the cooperative kernels do not carry.
-  long handoff = mk_opt(MK_OPT_HANDOFF);
-  if (handoff < 0) handoff = 4;
-  if (p->h_fused.any_posture_lm || mk_opt(MK_OPT_COOP) == 0) handoff = 0;
+  const long handoff = handoff_threshold(p);
   bool handed = false;
   MK_HIP(mk_fused_launch_iterate(p->nc_kernel, p->d_fused, p->info.nq, d_q, d_targets, p->info.target_stride, dt,
                                  damping, B, max_iters, pos_tol, ori_tol, d_v, d_iters, d_err, d_status,
@@ -1353,9 +1369,22 @@ int mk_move_to_batch(const mk_problem* p, double* d_q, const double* d_goals, co
   if (!d_q || !d_goals || !d_status) return fail(MK_ERR_INVALID, "null argument");
   if (!p->fused) return fail(MK_ERR_UNSUPPORTED, "waypoint reaching needs a problem the fused path serves");
   if (p->info.target_stride != 7) return fail(MK_ERR_UNSUPPORTED, "waypoint reaching drives exactly one frame task");
+  if (use_coop(p, B)) {
+    MK_HIP(mk_coop_launch_move_to(p->nc_kernel, p->d_fused, d_q, d_goals, dt, damping, B, max_steps, max_iters, pos_tol,
+                                  ori_tol, wp->pos_threshold, wp->pos_step_size, wp->rot_threshold, d_steps, d_reached,
+                                  d_solves, d_status, static_cast<hipStream_t>(stream)));
+    return MK_OK;
+  }
+  // the last rollouts of every wave finish on the cooperative kernel (second launch)
+  const long handoff = handoff_threshold(p);
+  bool handed = false;
   MK_HIP(mk_fused_launch_move_to(p->nc_kernel, p->d_fused, p->info.nq, d_q, d_goals, dt, damping, B, max_steps, max_iters,
                                  pos_tol, ori_tol, wp->pos_threshold, wp->pos_step_size, wp->rot_threshold, d_steps,
-                                 d_reached, d_solves, d_status, static_cast<hipStream_t>(stream)));
+                                 d_reached, d_solves, d_status, static_cast<hipStream_t>(stream), (int)handoff, &handed));
+  if (handed)
+    MK_HIP(mk_coop_launch_move_to_resume(p->nc_kernel, p->d_fused, d_q, d_goals, dt, damping, B, max_steps, max_iters,
+                                         pos_tol, ori_tol, wp->pos_threshold, wp->pos_step_size, wp->rot_threshold,
+                                         d_steps, d_reached, d_solves, d_status, 2048, static_cast<hipStream_t>(stream)));
   return MK_OK;
 }
 

@@ -938,6 +938,104 @@ MK_CO void coop_iterate_body(const MkFusedDesc* __restrict__ D, double* __restri
   }
 }
 
+// mk_move_to_batch on the cooperative form: waypoint reaching (envs/mj_env.py:193-276 with
+// envs/robot_utils.py:113-160) for problem pb.  Per outer step: the pose of the task frame, the
+// waypoint generator (bounded linear step, half-way slerp, reached test), then the callers' IK
+// loop towards the commanded pose; the problem stops after the step in which the generator
+// reported the goal reached, or after max_steps.  As in fused_move_to_kernel (mk_fused.hip) the
+// two nested loops are one flat sequence of ticks, one IK iteration each: a tick evaluates the
+// chain once, closes the outer step if its IK loop has ended on this pose, opens the next one on
+// the same pose, and solves.  steps0 / solves0 / status0: the rollout resumes at an outer-step
+// boundary after that many steps and solves (by the lane-per-problem kernel, see
+// coop_move_to_resume_kernel) with their worst status.
+template <int NC>
+MK_CO void coop_move_to_body(const MkFusedDesc* __restrict__ D, double* __restrict__ q, const double* __restrict__ goals,
+                             double dt, double damping, int max_steps, int max_iters, double pos_tol, double ori_tol,
+                             double wp_pos_thr, double wp_pos_step, double wp_rot_thr, int32_t* __restrict__ steps_out,
+                             int32_t* __restrict__ reached_out, int32_t* __restrict__ solves_out,
+                             int32_t* __restrict__ status_out, long pb, bool live, int steps0, int solves0, int status0) {
+  const int nq = D->nq;
+  const double inv_dt = 1.0 / dt;
+  CoLane<NC> C;
+  co_load_lane<NC>(D, C);
+  double* qrow = q + pb * nq;
+  CoProblem<NC> P;
+  co_load_problem<NC>(D, C, qrow, P);
+  const double* gp = goals + pb * 7;
+  const Q4 Qg = Q4{gp[0], gp[1], gp[2], gp[3]};
+  const V3 pg = v3(gp[4], gp[5], gp[6]);
+  Q4 Qt = Q4{1, 0, 0, 0};
+  V3 pt = v3(0, 0, 0);
+  int status = status0, steps = steps0, solves = solves0, it = 0;
+  bool alive = max_steps > steps0, now = false, reached = false, in_step = false;
+  const double pos_tol2 = pos_tol >= 0.0 ? pos_tol * pos_tol : -1.0, ori_tol2 = ori_tol >= 0.0 ? ori_tol * ori_tol : -1.0;
+  for (;;) {
+    if (alive) {
+      double Jc[6];
+      CoPose W;
+      co_chain<NC>(C, P.qc, Jc, W);
+      M3 Ji, Qm;
+      Twist e = Twist{v3(0, 0, 0), v3(0, 0, 0)};
+      // does the IK loop of the current outer step end on this pose?
+      bool begin = !in_step;
+      if (in_step) {
+        e = co_frame_error_jlog(W.q, W.t, Qt, pt, Ji, Qm);
+        const bool conv = it > 0 && dot(e.v, e.v) <= pos_tol2 && dot(e.w, e.w) <= ori_tol2;
+        if (conv || it == max_iters) {
+          ++steps;
+          if (now) {
+            reached = true;
+            alive = false;
+          } else if (steps == max_steps) {
+            alive = false;
+          } else {
+            begin = true;
+          }
+        }
+      }
+      if (begin) {
+        // the next outer step opens on the same pose: waypoint generator, then the error towards
+        // the new command
+        now = waypoint_step(W.q, W.t, Qg, pg, wp_pos_thr, wp_pos_step, wp_rot_thr, Qt, pt);
+        it = 0;
+        in_step = true;
+        if (max_iters == 0) {
+          // no IK iteration per step: the pose never changes, so every step repeats this one
+          if (now) { ++steps; reached = true; } else { steps = max_steps; }
+          alive = false;
+        }
+        e = co_frame_error_jlog(W.q, W.t, Qt, pt, Ji, Qm);
+      }
+      if (alive) {
+        double x, xd;
+        const int st = co_solve<NC>(
+            D, C, P, Jc, e, Ji, Qm, dt, damping, it > 0 || steps > steps0, x, xd,
+            [&](const MkDofC& dc) { return qrow[dc.qadr]; },
+            [&](const MkDofC& dc, double qi, double dq) { if (live) qrow[dc.qadr] = qi + dt * (dq * inv_dt); });
+        status = st > status ? st : status;
+        ++it;
+        ++solves;
+        P.qc = P.qc + dt * (x * inv_dt);
+        P.qd = P.qd + dt * (xd * inv_dt);
+      }
+    }
+    if (mk_wave_none(alive)) break;
+  }
+  if (live) {
+    if (solves > solves0) {
+      if (C.dof >= 0) qrow[C.qadr] = P.qc;
+      if (P.has_dd) qrow[P.dd.qadr] = P.qd;
+      co_free_renorm(D, qrow);
+    }
+    if (co_lane() == 0) {
+      status_out[pb] = status;
+      if (steps_out) steps_out[pb] = steps;
+      if (reached_out) reached_out[pb] = reached ? 1 : 0;
+      if (solves_out) solves_out[pb] = solves;
+    }
+  }
+}
+
 #if !defined(MK_COOP_NO_KERNELS)
 template <int NC>
 __global__ __launch_bounds__(64) void coop_step_kernel(const MkFusedDesc* __restrict__ D, const double* __restrict__ q,
@@ -959,6 +1057,49 @@ __global__ __launch_bounds__(64) void coop_iterate_kernel(const MkFusedDesc* __r
   const bool live = g < B;   // a row without a problem repeats the last one and stores nothing
   coop_iterate_body<NC>(D, q, targets, target_stride, dt, damping, max_iters, pos_tol, ori_tol, v_out, iters_out, err_out,
                         status_out, live ? g : B - 1, live, 0, 0);
+}
+
+template <int NC>
+__global__ __launch_bounds__(64) void coop_move_to_kernel(const MkFusedDesc* __restrict__ D, double* __restrict__ q,
+                                                          const double* __restrict__ goals, double dt, double damping,
+                                                          int B, int max_steps, int max_iters, double pos_tol,
+                                                          double ori_tol, double wp_pos_thr, double wp_pos_step,
+                                                          double wp_rot_thr, int32_t* __restrict__ steps_out,
+                                                          int32_t* __restrict__ reached_out,
+                                                          int32_t* __restrict__ solves_out,
+                                                          int32_t* __restrict__ status_out) {
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 4);
+  const bool live = g < B;
+  coop_move_to_body<NC>(D, q, goals, dt, damping, max_steps, max_iters, pos_tol, ori_tol, wp_pos_thr, wp_pos_step,
+                        wp_rot_thr, steps_out, reached_out, solves_out, status_out, live ? g : B - 1, live, 0, 0, 0);
+}
+
+// The rollouts that fused_move_to_kernel (mk_fused.hip) left at an outer-step boundary, marked
+// with MK_ITER_CONT_BIT in steps_out: found and shared out like the problems of coop_resume_kernel.
+template <int NC>
+__global__ __launch_bounds__(64) void coop_move_to_resume_kernel(
+    const MkFusedDesc* __restrict__ D, double* __restrict__ q, const double* __restrict__ goals, double dt, double damping,
+    int B, int max_steps, int max_iters, double pos_tol, double ori_tol, double wp_pos_thr, double wp_pos_step,
+    double wp_rot_thr, int32_t* __restrict__ steps_out, int32_t* __restrict__ reached_out,
+    int32_t* __restrict__ solves_out, int32_t* __restrict__ status_out) {
+  const int row = threadIdx.x >> 4;
+  const int nchunks = (B + 63) / 64;
+  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const long idx = (long)ch * 64 + threadIdx.x;
+    const int32_t mark = idx < B ? steps_out[idx] : 0;
+    uint64_t mask = __ballot((mark & MK_ITER_CONT_BIT) != 0);
+    while (mask != 0ull) {   // wave-uniform
+      uint64_t m = mask;
+      for (int k = 0; k < row; ++k) m &= m - 1ull;
+      if (m != 0ull) {
+        const long pb = (long)ch * 64 + (__ffsll((unsigned long long)m) - 1);
+        coop_move_to_body<NC>(D, q, goals, dt, damping, max_steps, max_iters, pos_tol, ori_tol, wp_pos_thr, wp_pos_step,
+                              wp_rot_thr, steps_out, reached_out, solves_out, status_out, pb, true,
+                              steps_out[pb] & ~MK_ITER_CONT_BIT, solves_out[pb], status_out[pb]);
+      }
+      for (int k = 0; k < 4; ++k) mask &= mask - 1ull;
+    }
+  }
 }
 
 // Second phase of the callers' loop on batches that fill the machine's lanes once: the
@@ -1029,6 +1170,47 @@ hipError_t mk_coop_launch_iterate(int nc, const MkFusedDesc* d_desc, double* q, 
   case N:                                                                                                               \
     hipLaunchKernelGGL(coop_iterate_kernel<N>, dim3(blocks), dim3(64), 0, stream, d_desc, q, targets, target_stride,    \
                        dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status);                             \
+    break;
+    MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
+#undef MK_CASE
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t mk_coop_launch_move_to(int nc, const MkFusedDesc* d_desc, double* q, const double* goals, double dt,
+                                  double damping, int B, int max_steps, int max_iters, double pos_tol, double ori_tol,
+                                  double wp_pos_thr, double wp_pos_step, double wp_rot_thr, int32_t* steps,
+                                  int32_t* reached, int32_t* solves, int32_t* status, hipStream_t stream) {
+  const int blocks = (B + 3) / 4;
+  switch (nc) {
+#define MK_CASE(N)                                                                                                      \
+  case N:                                                                                                               \
+    hipLaunchKernelGGL(coop_move_to_kernel<N>, dim3(blocks), dim3(64), 0, stream, d_desc, q, goals, dt, damping, B,     \
+                       max_steps, max_iters, pos_tol, ori_tol, wp_pos_thr, wp_pos_step, wp_rot_thr, steps, reached,     \
+                       solves, status);                                                                                 \
+    break;
+    MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
+#undef MK_CASE
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// The rollouts that a lane-per-problem launch marked with MK_ITER_CONT_BIT in `steps`.
+hipError_t mk_coop_launch_move_to_resume(int nc, const MkFusedDesc* d_desc, double* q, const double* goals, double dt,
+                                         double damping, int B, int max_steps, int max_iters, double pos_tol,
+                                         double ori_tol, double wp_pos_thr, double wp_pos_step, double wp_rot_thr,
+                                         int32_t* steps, int32_t* reached, int32_t* solves, int32_t* status,
+                                         int max_blocks, hipStream_t stream) {
+  const int nchunks = (B + 63) / 64;
+  const int blocks = nchunks < max_blocks ? nchunks : max_blocks;
+  switch (nc) {
+#define MK_CASE(N)                                                                                                      \
+  case N:                                                                                                               \
+    hipLaunchKernelGGL(coop_move_to_resume_kernel<N>, dim3(blocks), dim3(64), 0, stream, d_desc, q, goals, dt, damping, \
+                       B, max_steps, max_iters, pos_tol, ori_tol, wp_pos_thr, wp_pos_step, wp_rot_thr, steps, reached,  \
+                       solves, status);                                                                                 \
     break;
     MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
 #undef MK_CASE

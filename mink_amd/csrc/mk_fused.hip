@@ -1738,7 +1738,14 @@ __global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __
 // opens the next one on the same pose (waypoint generator), and solves.  Lanes whose problem
 // is finished take the next problem of the wave's chunk, as in fused_iterate_stream_kernel.
 // A problem's arithmetic does not depend on the lane or the company it runs in.
-template <int NC>
+//
+// HANDOFF: once a wave has handed out its whole chunk and no more than `handoff_live` of its
+// rollouts are still running, each of those leaves the kernel at its next outer-step boundary
+// (where its state is just q and the three counters) with MK_ITER_CONT_BIT set in its steps_out
+// entry; the cooperative kernel (coop_move_to_resume_kernel, mk_coop.hip) runs it to the end at
+// 16 lanes per rollout instead of holding a 64-lane wave for its remaining sequential solves.
+// steps_out and solves_out must be given.
+template <int NC, bool HANDOFF = false>
 __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restrict__ D_arg, double* __restrict__ q,
                                                     const double* __restrict__ goals, double dt, double damping,
                                                     int B, int chunk, int refill_min, int max_steps, int max_iters,
@@ -1747,7 +1754,7 @@ __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restric
                                                     int32_t* __restrict__ steps_out,
                                                     int32_t* __restrict__ reached_out,
                                                     int32_t* __restrict__ solves_out,
-                                                    int32_t* __restrict__ status_out) {
+                                                    int32_t* __restrict__ status_out, int handoff_live = 0) {
   const MkFusedDesc* D = D_arg;
   extern __shared__ double tile[];
   const int nq = D->nq;
@@ -1760,7 +1767,7 @@ __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restric
   const long last = min((long)B, next + (long)chunk);
   const bool sync_rows = D->any_posture_lm != 0;
   long pid = -1;                                   // -1: nothing yet, -2: chunk exhausted
-  bool live = false, input_bad = false, now = false, reached = false, in_step = false;
+  bool live = false, input_bad = false, now = false, reached = false, in_step = false, handed = false;
   double qc[NC], x[NC];
 #pragma unroll
   for (int k = 0; k < NC; ++k) { qc[k] = 0.0; x[k] = 0.0; }
@@ -1776,7 +1783,7 @@ __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restric
         store_chain_q<NC>(D, row, qc);
         lane_copy(q + pid * nq, row, nq);
         status_out[pid] = status;
-        if (steps_out) steps_out[pid] = steps;
+        if (steps_out) steps_out[pid] = (HANDOFF && handed) ? (steps | MK_ITER_CONT_BIT) : steps;
         if (reached_out) reached_out[pid] = reached ? 1 : 0;
         if (solves_out) solves_out[pid] = solves;
       }
@@ -1793,7 +1800,7 @@ __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restric
           input_bad = rest_nonfinite(D, row);
           status = 0; steps = 0; solves = 0; it = 0;
           act = 0u; upper = 0u;
-          now = false; reached = false; in_step = false;
+          now = false; reached = false; in_step = false; handed = false;
           live = max_steps > 0;     // no outer step at all: the problem goes straight back
         } else {
           pid = -2;
@@ -1805,6 +1812,8 @@ __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restric
       continue;
     }
     const MkFusedDesc* __restrict__ Di = D_arg + mk_opaque_zero();
+    // the wave's tail: nothing left to hand out and few rollouts still running (wave-uniform)
+    const bool tail = HANDOFF && next >= last && __popcll(__ballot(live)) <= handoff_live;
     if (live) {
       ChainJac<NC> cj;
       Q4 Q;
@@ -1827,6 +1836,12 @@ __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restric
             begin = true;
           }
         }
+      }
+      if (HANDOFF && tail && begin) {
+        // outer-step boundary in the tail: the cooperative kernel takes the rollout from here
+        handed = true;
+        live = false;
+        begin = false;
       }
       if (begin) {
         // the next outer step opens on the same pose: waypoint generator, then the error
@@ -2044,7 +2059,8 @@ template <int NC>
 static hipError_t launch_move_to(const MkFusedDesc* d_desc, int nq, double* q, const double* goals, double dt,
                                  double damping, int B, int max_steps, int max_iters, double pos_tol, double ori_tol,
                                  double wp_pos_thr, double wp_pos_step, double wp_rot_thr, int32_t* steps,
-                                 int32_t* reached, int32_t* solves, int32_t* status, hipStream_t stream) {
+                                 int32_t* reached, int32_t* solves, int32_t* status, hipStream_t stream,
+                                 int handoff_live) {
   // one persistent wave per wave slot of the device at most; with fewer problems than lanes
   // every lane gets exactly one problem
   int slots = wave_slots();
@@ -2053,10 +2069,17 @@ static hipError_t launch_move_to(const MkFusedDesc* d_desc, int nq, double* q, c
   const int chunk = (B + blocks - 1) / blocks;
   const int refill_min = (int)mk_opt(MK_OPT_STREAM_REFILL);   // tuning
   const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
-  if (hipError_t e = allow_lds<fused_move_to_kernel<NC>>(lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL(fused_move_to_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, goals, dt, damping, B,
-                     chunk, refill_min, max_steps, max_iters, pos_tol, ori_tol, wp_pos_thr, wp_pos_step, wp_rot_thr,
-                     steps, reached, solves, status);
+  if (handoff_live > 0) {
+    if (hipError_t e = allow_lds<fused_move_to_kernel<NC, true>>(lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL((fused_move_to_kernel<NC, true>), dim3(blocks), dim3(64), lds, stream, d_desc, q, goals, dt,
+                       damping, B, chunk, refill_min, max_steps, max_iters, pos_tol, ori_tol, wp_pos_thr, wp_pos_step,
+                       wp_rot_thr, steps, reached, solves, status, handoff_live);
+    return hipGetLastError();
+  }
+  if (hipError_t e = allow_lds<fused_move_to_kernel<NC, false>>(lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((fused_move_to_kernel<NC, false>), dim3(blocks), dim3(64), lds, stream, d_desc, q, goals, dt,
+                     damping, B, chunk, refill_min, max_steps, max_iters, pos_tol, ori_tol, wp_pos_thr, wp_pos_step,
+                     wp_rot_thr, steps, reached, solves, status, 0);
   return hipGetLastError();
 }
 
@@ -2064,12 +2087,16 @@ hipError_t mk_fused_launch_move_to(int nc, const MkFusedDesc* d_desc, int nq, do
                                    double dt, double damping, int B, int max_steps, int max_iters, double pos_tol,
                                    double ori_tol, double wp_pos_thr, double wp_pos_step, double wp_rot_thr,
                                    int32_t* steps, int32_t* reached, int32_t* solves, int32_t* status,
-                                   hipStream_t stream) {
+                                   hipStream_t stream, int handoff_live, bool* handed) {
+  // (the marks of the hand-off live in `steps`, and the resumed rollout continues its counters)
+  if (!(handoff_live > 0 && steps != nullptr && solves != nullptr && max_iters > 0)) handoff_live = 0;
+  if (handed) *handed = handoff_live > 0;
   switch (nc) {
 #define MK_CASE(N)                                                                                              \
   case N:                                                                                                       \
     return launch_move_to<N>(d_desc, nq, q, goals, dt, damping, B, max_steps, max_iters, pos_tol, ori_tol,     \
-                             wp_pos_thr, wp_pos_step, wp_rot_thr, steps, reached, solves, status, stream);
+                             wp_pos_thr, wp_pos_step, wp_rot_thr, steps, reached, solves, status, stream,      \
+                             handoff_live);
     MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
 #undef MK_CASE
     default: return hipErrorInvalidValue;

@@ -72,8 +72,17 @@ def test_device_waypoint_step_matches_reference_code():
         assert bool(reached[b]) == done
 
 
+@pytest.fixture(params=["lane", "coop"])
+def kernel_form(request):
+    """Both forms of the one-launch kernels: one rollout per lane (mk_fused.hip) and one per
+    16-lane row (mk_coop.hip)."""
+    from mink_amd import _lib as L
+    with L.options(coop=1 if request.param == "coop" else 0):
+        yield request.param
+
+
 @pytest.mark.gpu
-def test_move_to_matches_sequential_reference_loop():
+def test_move_to_matches_sequential_reference_loop(kernel_form):
     import mink_amd as mink
     from mink_amd import workloads as W
     from oracle import ik_oracle as o
@@ -122,7 +131,7 @@ def test_move_to_matches_sequential_reference_loop():
 
 
 @pytest.mark.gpu
-def test_move_to_single_launch_matches_stepwise():
+def test_move_to_single_launch_matches_stepwise(kernel_form):
     """The one-launch form (mk_move_to_batch) against the host loop over outer steps, on a
     batch large enough to have ragged blocks and every outcome (reached early, late, not)."""
     import mink_amd as mink
@@ -154,3 +163,36 @@ def test_move_to_single_launch_matches_stepwise():
     cfg_c = mink.Configuration(model, q0[:4])
     c = mink.move_to(cfg_c, frame, [frame, rel, posture], goal_pos[:4], SO3(goal_rot.wxyz[:4]), CFG, max_steps=3)
     assert int(c["steps"].max()) <= 3 and int(c["solves"].sum()) > 0
+
+
+@pytest.mark.gpu
+def test_move_to_tail_handoff_matches_lane_kernel():
+    """Beyond the cooperative kernels' batch size the lane kernel hands the last rollouts of
+    each wave to the cooperative kernel at an outer-step boundary: same step / solve counts and
+    end configurations as the lane kernel alone (the two differ in rounding only; a rollout whose
+    own dynamics amplify the last bits may take one solve more or less)."""
+    import mink_amd as mink
+    from mink_amd import _lib as L
+    from mink_amd import workloads as W
+    model = mink.load_builtin("tidybot_cube")
+    rng = np.random.default_rng(11)
+    B, max_steps = 16384 + 3000, 30
+    q0 = W.sample_q(model, rng, B)
+    frame = mink.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0)
+    posture = mink.PostureTask(model, cost=W.posture_cost(model))
+    posture.set_target(W.home_q(model))
+    cfg_a, cfg_b = mink.Configuration(model, q0), mink.Configuration(model, q0)
+    start = cfg_a.get_transform_frame_to_world("pinch_site", "site")
+    goal_pos = start.translation() + torch.tensor(rng.uniform(-0.25, 0.25, (B, 3)), device="cuda:0")
+    goal_rot = start.rotation() @ SO3.exp(torch.tensor(rng.uniform(-0.6, 0.6, (B, 3)), device="cuda:0"))
+    with L.options(coop=0):
+        a = mink.move_to(cfg_a, frame, [frame, posture], goal_pos, goal_rot, CFG, max_steps=max_steps)
+    b = mink.move_to(cfg_b, frame, [frame, posture], goal_pos, goal_rot, CFG, max_steps=max_steps)
+    assert int(b["steps"].max()) <= max_steps and int(b["steps"].min()) >= 1     # no mark left behind
+    same = (a["steps"] == b["steps"]) & (a["solves"] == b["solves"]) & (a["reached"] == b["reached"])
+    print("rollouts with equal counts:", int(same.sum()), "of", B, "; solves max", int(a["solves"].max()),
+          "mean", float(a["solves"].double().mean()))
+    assert float(same.double().mean()) >= 0.9995
+    dq = (cfg_a.q - cfg_b.q).abs().amax(dim=1)[same]
+    assert float(dq.max()) <= 1e-7
+    assert int(a["solves"].max()) > 3 * float(a["solves"].double().mean())     # there is a tail to hand off
