@@ -1622,7 +1622,12 @@ MK_DEV void lane_copy(double* __restrict__ dst, const double* __restrict__ src, 
 // fused_iterate_kernel, whatever lane and company it runs in: results are bit-identical.
 // The next problem index is wave-uniform state (one wave per block), so handing out
 // problems needs neither atomics nor memory.
-template <int NC>
+//
+// HANDOFF: once a wave has handed out its whole chunk and no more than `handoff_live` of its
+// problems are still in the loop, those leave the kernel marked MK_ITER_CONT_BIT in iters_out
+// (which must be given) and finish on the cooperative kernel (coop_resume_kernel, mk_coop.hip),
+// as in fused_iterate_kernel.
+template <int NC, bool HANDOFF = false>
 __global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __restrict__ D_arg,
                                                            double* __restrict__ q,
                                                            const double* __restrict__ targets, int target_stride,
@@ -1630,7 +1635,7 @@ __global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __
                                                            int max_iters, double pos_tol, double ori_tol,
                                                            double* __restrict__ v_out, int32_t* __restrict__ iters_out,
                                                            double* __restrict__ err_out,
-                                                           int32_t* __restrict__ status_out) {
+                                                           int32_t* __restrict__ status_out, int handoff_live = 0) {
   const MkFusedDesc* D = D_arg;
   extern __shared__ double tile[];
   const int nq = D->nq, nv = D->nv;
@@ -1643,7 +1648,7 @@ __global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __
   const long last = min((long)B, next + (long)chunk);
   const bool sync_rows = D->any_posture_lm != 0;
   long pid = -1;                                              // -1: nothing yet, -2: chunk exhausted
-  bool live = false, input_bad = false;
+  bool live = false, input_bad = false, handed = false;
   double qc[NC], x[NC];
 #pragma unroll
   for (int k = 0; k < NC; ++k) { qc[k] = 0.0; x[k] = 0.0; }
@@ -1669,7 +1674,7 @@ __global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __
             if (D->seg_dof[k] >= 0) vr[D->seg_dof[k]] = x[k];
         }
         status_out[pid] = status;
-        if (iters_out) iters_out[pid] = iters;
+        if (iters_out) iters_out[pid] = (HANDOFF && handed) ? (iters | MK_ITER_CONT_BIT) : iters;
         if (err_out) {
           double* eo = err_out + pid * 6;
           eo[0] = e.v.x; eo[1] = e.v.y; eo[2] = e.v.z; eo[3] = e.w.x; eo[4] = e.w.y; eo[5] = e.w.z;
@@ -1692,6 +1697,7 @@ __global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __
           status = 0; iters = 0; it = 0;
           act = 0u; upper = 0u;
           live = true;
+          handed = false;
         } else {
           pid = -2;
         }
@@ -1699,12 +1705,17 @@ __global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __
     }
     if (__ballot(live) == 0ull) break;
     const MkFusedDesc* __restrict__ Di = D_arg + mk_opaque_zero();   // same descriptor, re-read per pass
+    // the wave's tail: nothing left to hand out and few problems still in the loop (wave-uniform)
+    const bool tail = HANDOFF && next >= last && __popcll(__ballot(live)) <= handoff_live;
     if (live) {
       ChainJac<NC> cj;
       chain_jac<NC>(Di, qc, Qt, pt, cj);
       e = cj.e;
       const bool conv = it > 0 && sqrt(dot(e.v, e.v)) <= pos_tol && sqrt(dot(e.w, e.w)) <= ori_tol;
       if (conv || it == max_iters) {
+        live = false;
+      } else if (HANDOFF && tail) {
+        handed = true;
         live = false;
       } else {
         double* vrow = v_out ? v_out + pid * nv : nullptr;
@@ -1931,14 +1942,21 @@ template <int NC>
 static hipError_t launch_iterate_stream(const MkFusedDesc* d_desc, int nq, double* q, const double* targets,
                                         int target_stride, double dt, double damping, int B, int blocks, int max_iters,
                                         double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
-                                        int32_t* status, hipStream_t stream) {
+                                        int32_t* status, hipStream_t stream, int handoff_live) {
   const int chunk = (B + blocks - 1) / blocks;
   const int refill_min = (int)mk_opt(MK_OPT_STREAM_REFILL);   // tuning
   const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
-  if (hipError_t e = allow_lds<fused_iterate_stream_kernel<NC>>(lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL(fused_iterate_stream_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
+  if (handoff_live > 0) {
+    if (hipError_t e = allow_lds<fused_iterate_stream_kernel<NC, true>>(lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL((fused_iterate_stream_kernel<NC, true>), dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
+                       target_stride, dt, damping, B, chunk, refill_min, max_iters, pos_tol, ori_tol, v, iters, err,
+                       status, handoff_live);
+    return hipGetLastError();
+  }
+  if (hipError_t e = allow_lds<fused_iterate_stream_kernel<NC, false>>(lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((fused_iterate_stream_kernel<NC, false>), dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
                      target_stride, dt, damping, B, chunk, refill_min, max_iters, pos_tol, ori_tol, v, iters, err,
-                     status);
+                     status, 0);
   return hipGetLastError();
 }
 
@@ -2019,7 +2037,8 @@ hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, do
                                    int target_stride, double dt, double damping, int B, int max_iters,
                                    double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
                                    int32_t* status, hipStream_t stream, int handoff_live, bool* handed) {
-  if (handed) *handed = false;
+  if (!(handoff_live > 0 && iters != nullptr && pos_tol >= 0.0 && ori_tol >= 0.0 && max_iters > 2)) handoff_live = 0;
+  if (handed) *handed = handoff_live > 0;
   // With an exit test and more problems than twice the lanes of the machine, lanes stream
   // through the problems of a chunk (one persistent wave per slot); otherwise one block of 64
   // problems per wave with coalesced tile copies.
@@ -2036,14 +2055,12 @@ hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, do
 #define MK_CASE(N)                                                                                              \
   case N:                                                                                                       \
     return launch_iterate_stream<N>(d_desc, nq, q, targets, target_stride, dt, damping, B, slots, max_iters,  \
-                                    pos_tol, ori_tol, v, iters, err, status, stream);
+                                    pos_tol, ori_tol, v, iters, err, status, stream, handoff_live);
       MK_CASE(4) MK_CASE(6) MK_CASE(7) MK_CASE(8) MK_CASE(10) MK_CASE(12)
 #undef MK_CASE
       default: return hipErrorInvalidValue;
     }
   }
-  if (!(handoff_live > 0 && iters != nullptr && pos_tol >= 0.0 && ori_tol >= 0.0 && max_iters > 2)) handoff_live = 0;
-  if (handed) *handed = handoff_live > 0;
   switch (nc) {
 #define MK_CASE(N)                                                                                         \
   case N:                                                                                                  \

@@ -187,11 +187,14 @@ def test_default_is_by_batch_size(env):
     assert torch.equal(v_lane, v_big[:nmax])
 
 
-@pytest.mark.parametrize("B,handoff", [(65536, -1), (20000, 9), (65536 + 77, 1)])
-def test_wave_handoff_to_cooperative_kernel(env, B, handoff):
+@pytest.mark.parametrize("B,handoff,stream", [(65536, -1, 0), (20000, 9, 0), (65536 + 77, 1, 0), (40000, -1, 96),
+                                              (300000, -1, -1)])
+def test_wave_handoff_to_cooperative_kernel(env, B, handoff, stream):
     """Loops with an exit test on batches beyond the cooperative kernels' size: the lane kernel
     stops a wave when few of its problems are left and the cooperative kernel finishes those.
-    Same solve counts and configurations as the lane kernel alone."""
+    Same solve counts and configurations as the lane kernel alone.  stream: the block-per-64
+    kernel (0), the lane-streaming kernel with that many persistent waves, or the library's choice
+    (-1; streaming at 300000 problems) -- the streaming kernel hands over the tail of each chunk."""
     from mink_amd.engine import DeviceProblem
     model, dm = env
     rng = np.random.default_rng(77)
@@ -205,8 +208,8 @@ def test_wave_handoff_to_cooperative_kernel(env, B, handoff):
             r = prob.iterate_(q, targets, W.DT, W.DAMPING, 20, 1e-4, 1e-4, want_v=True)
         return q, r
 
-    ql, rl = run(coop=0)
-    qh, rh = run(handoff=handoff)
+    ql, rl = run(coop=0, stream_blocks=stream)
+    qh, rh = run(handoff=handoff, stream_blocks=stream)
     assert int(rh["iters"].max()) <= 20 and int(rh["iters"].min()) >= 1      # no mark left behind
     assert torch.equal(rl["iters"], rh["iters"])
     assert torch.equal(rl["status"], rh["status"])
@@ -214,5 +217,5 @@ def test_wave_handoff_to_cooperative_kernel(env, B, handoff):
     assert float((rl["err"] - rh["err"]).abs().max()) <= 1e-10
     assert float((rl["v"] - rh["v"]).abs().max()) <= 1e-8
     # and the hand-off did happen: with it switched off the launch is the lane kernel's, bit for bit
-    q0_, r0_ = run(handoff=0)
+    q0_, r0_ = run(handoff=0, stream_blocks=stream)
     assert torch.equal(q0_, ql)

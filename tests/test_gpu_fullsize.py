@@ -72,8 +72,13 @@ def test_config3_size_batch_invariance_kkt_and_limits(env):
     v, st = prob.solve(q0, tg, W.DT, W.DAMPING)
     assert int(st.abs().sum()) == 0
     lo, n = 20011, 4099            # odd offset and size: not aligned with the 64-problem blocks
-    v_s, st_s = prob.solve(q0[lo:lo + n].contiguous(), tg[lo:lo + n].contiguous(), W.DT, W.DAMPING)
+    # (a batch of this size alone would go to the cooperative kernels: bit-equality is a property
+    # of one kernel form, equality to rounding holds across the two)
+    with L.options(coop=0):
+        v_s, st_s = prob.solve(q0[lo:lo + n].contiguous(), tg[lo:lo + n].contiguous(), W.DT, W.DAMPING)
     assert torch.equal(v_s, v[lo:lo + n])
+    v_c, st_c = prob.solve(q0[lo:lo + n].contiguous(), tg[lo:lo + n].contiguous(), W.DT, W.DAMPING)
+    assert float((v_c - v_s).abs().max()) <= 1e-9 and int(st_c.abs().sum()) == 0
     # KKT of the minimiser on a strided sample
     idx = torch.arange(0, B, 37, device=DEV)[:1536]
     P, c, G, h = prob.build_qp(q0[idx].contiguous(), tg[idx].contiguous(), W.DT, W.DAMPING)
@@ -86,8 +91,12 @@ def test_config3_size_batch_invariance_kkt_and_limits(env):
     res = prob.iterate_(q, tg, W.DT, W.DAMPING, K, want_v=True)
     assert int(res["status"].abs().sum()) == 0 and int((res["iters"] != K).sum()) == 0
     qs = q0[lo:lo + n].clone()
-    res_s = prob.iterate_(qs, tg[lo:lo + n].contiguous(), W.DT, W.DAMPING, K, want_v=True)
+    with L.options(coop=0):
+        res_s = prob.iterate_(qs, tg[lo:lo + n].contiguous(), W.DT, W.DAMPING, K, want_v=True)
     assert torch.equal(qs, q[lo:lo + n]) and torch.equal(res_s["err"], res["err"][lo:lo + n])
+    qc = q0[lo:lo + n].clone()
+    prob.iterate_(qc, tg[lo:lo + n].contiguous(), W.DT, W.DAMPING, K)      # cooperative kernels
+    assert float((qc - qs).abs().max()) <= 1e-9
     rng_lo = torch.tensor(model.jnt_range[:, 0], device=DEV)
     rng_hi = torch.tensor(model.jnt_range[:, 1], device=DEV)
     for j in range(model.njnt):
@@ -159,9 +168,13 @@ def test_config5_shard_size_fixed_point_and_invariance(env):
     ra = prob5.iterate_(qa, tg0, W.DT, W.DAMPING, 50)
     lo, n = 77777, 1000
     qb = q0[lo:lo + n].clone()
-    prob5.iterate_(qb, tg0[lo:lo + n].contiguous(), W.DT, W.DAMPING, 50)
+    with L.options(coop=0):
+        prob5.iterate_(qb, tg0[lo:lo + n].contiguous(), W.DT, W.DAMPING, 50)
     assert int(ra["status"].abs().sum()) == 0
     assert torch.equal(qb, qa[lo:lo + n])
+    qc = q0[lo:lo + n].clone()
+    prob5.iterate_(qc, tg0[lo:lo + n].contiguous(), W.DT, W.DAMPING, 50)   # cooperative kernels
+    assert float((qc - qb).abs().max()) <= 1e-9
 
 
 def test_config5_full_batch_one_launch_and_shard_invariance(env):

@@ -81,7 +81,8 @@ def test_stream_path_is_taken_for_large_batches_and_matches(env):
     n = 1 << 18
     q0, tg = near_inputs(model, dm, n, 22)
     q = q0.clone()
-    res = prob.iterate_(q, tg, W.DT, W.DAMPING, 20, 1e-4, 1e-4)
+    with L.options(coop=0):   # lane kernels alone (no hand-off of the tails to the cooperative kernel)
+        res = prob.iterate_(q, tg, W.DT, W.DAMPING, 20, 1e-4, 1e-4)
     lo, m = 100003, 4099
     q_b, res_b = run(prob, q0[lo:lo + m].contiguous(), tg[lo:lo + m].contiguous(), 20, 0)
     assert torch.equal(q_b, q[lo:lo + m]) and torch.equal(res_b["iters"], res["iters"][lo:lo + m])

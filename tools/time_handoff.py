@@ -13,7 +13,7 @@ dev = "cuda:0"
 model = load_builtin("tidybot_cube")
 dm = DeviceModel(model, dev)
 rng = np.random.default_rng(4)
-BMAX = 131072
+BMAX = max([int(a) for a in sys.argv[1:]] + [131072])
 q0 = torch.tensor(W.sample_q(model, rng, BMAX), device=dev)
 near = torch.tensor(W.offset_targets(dm.frame_pose(q0, 2, model.site_id("pinch_site")).cpu().numpy(), rng), device=dev)
 pn = DeviceProblem(dm, W.task_specs(model, False), W.limit_specs(model, False))
