@@ -37,6 +37,7 @@ FLOP_PER_SOLVE = 14.8e3
 BYTES_PER_SOLVE = 648.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = 1/2 of the 157.3 TF fp32 vector peak
 HBM_PEAK_GBS = 8000.0
+ONE_WAVE_FMA_TFLOPS = 62.0       # measured: pure fp64 FMA stream at one wave per SIMD (75 at four waves per SIMD)
 KERNEL_SOURCES = ("mink_amd/csrc/mk_fused.hip", "mink_amd/csrc/mk_device.h")
 
 
@@ -240,7 +241,12 @@ def other_workloads(model, dm, prob, q0, targets, out, device, barrier):
     q2, t2 = q0[:4096].contiguous(), targets[:4096].contiguous()
     w2, e2 = time_launches(lambda i: p2.solve(q2, t2, W.DT, W.DAMPING, v=v, status=st), 200, 20, barrier)
     extra["config2_B4096_single_step"] = {"solves_per_s": 4096 * 200 / w2, "us_per_launch": 1e6 * e2 / 200,
-                                          "kkt": kkt_residual(p2, q2, t2, v * W.DT, W)}
+                                          "kkt": kkt_residual(p2, q2, t2, v * W.DT, W),
+                                          "kernel": "coop_step_kernel<10> (16 lanes per problem; the library's "
+                                                    "choice up to 16384 problems)"}
+    with L.options(coop=0):
+        w2l, e2l = time_launches(lambda i: p2.solve(q2, t2, W.DT, W.DAMPING, v=v, status=st), 200, 20, barrier)
+    extra["config2_B4096_single_step"]["lane_kernel_us_per_launch"] = 1e6 * e2l / 200
     # benchmark config 3: 65536 problems x 50 iterated steps (far targets, fixed work), then the same with
     # the early exit
     q3 = [q0[:65536].clone() for _ in range(6)]
@@ -275,9 +281,15 @@ def other_workloads(model, dm, prob, q0, targets, out, device, barrier):
               status=torch.empty(Bn, dtype=torch.int32, device=device))
     wn, en = time_launches(lambda i: pn.iterate_(qn[i], tn, W.DT, W.DAMPING, 20, 1e-4, 1e-4, out=on), 5, 2, barrier)
     stats_n = loop_stats(on)
+    for b in qn:
+        b.copy_(q0[:Bn])
+    with L.options(coop=0):
+        wl_, el_ = time_launches(lambda i: pn.iterate_(qn[i], tn, W.DT, W.DAMPING, 20, 1e-4, 1e-4, out=on), 5, 2, barrier)
     extra["near_target_loop_B65536"] = dict(
         stats_n, ms_per_launch=1e3 * en / 5, solves_per_s=Bn * stats_n["mean_solves"] * 5 / wn,
-        problems_per_s=Bn * 5 / wn,
+        problems_per_s=Bn * 5 / wn, lane_kernel_alone_ms_per_launch=1e3 * el_ / 5,
+        kernels="fused_iterate_kernel<10, hand-off> then coop_resume_kernel<10>: a wave of the lane kernel stops when "
+                "4 or fewer of its problems are left and the cooperative kernel finishes those",
         note="offset targets (<= 0.17 m, <= 0.52 rad), FrameTask + PostureTask, default ConfigurationLimit, "
              "<= 20 iterations with the 1e-4 / 1e-4 exit test (interactive_scripts/teleop_mouse.py:105-121); "
              "solves counted as executed")
@@ -493,9 +505,14 @@ def main():
                          "frac": kernel_rate * FLOP_PER_SOLVE / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                          "traffic": None, "kernel": "fused_iterate_kernel<10>",
                          "kernel_ms": 1e3 * kernel_s, "flop_per_solve": FLOP_PER_SOLVE,
-                         "hbm": {"achieved": kernel_rate * BYTES_PER_SOLVE / 1e9, "peak": HBM_PEAK_GBS,
-                                 "unit": "GB/s", "frac": kernel_rate * BYTES_PER_SOLVE / 1e9 / HBM_PEAK_GBS,
-                                 "bytes_per_solve": BYTES_PER_SOLVE}},
+                         # what the occupancy of this kernel (one wave per SIMD) allows: a stream of nothing
+                         # but fp64 FMAs measured on this machine (tools/ubench/fma_latency.hip)
+                         "ceiling_one_wave_tflops": ONE_WAVE_FMA_TFLOPS,
+                         # HBM side, from the measured traffic below when there is one; the per-solve
+                         # figure of the I/O convention (q in, target in, v and q' out) is kept beside it
+                         "hbm": {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                                 "algorithmic_bytes_per_solve": BYTES_PER_SOLVE,
+                                 "algorithmic_rate_GBs": kernel_rate * BYTES_PER_SOLVE / 1e9}},
             "solver_status_nonzero": int(stats["bad"]),
             "solves_executed_per_step": int(stats["solves"]),
             "final_err_max": {"pos": stats["pos"], "ori": stats["ori"]},
@@ -512,6 +529,8 @@ def main():
                 scale = B / tj["problems_per_launch"]      # traffic and flops are per problem
                 rl["traffic"] = tj["hbm_bytes_per_launch"] * scale
                 rl["traffic_note"] = tj.get("note")
+                rl["hbm"]["achieved"] = rl["traffic"] / kernel_s / 1e9
+                rl["hbm"]["frac"] = rl["hbm"]["achieved"] / HBM_PEAK_GBS
                 if tj.get("executed_flop_per_solve"):
                     rl["executed_flop_per_solve"] = tj["executed_flop_per_solve"]
                     rl["executed_achieved"] = kernel_rate * tj["executed_flop_per_solve"] / 1e12

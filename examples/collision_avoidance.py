@@ -55,7 +55,6 @@ for attempt in range(2):                      # the first call also builds and c
                                 pos_threshold=1e-4, ori_threshold=1e-4)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-cfg.check()                                   # deferred solver status of the batched calls
 h = torch.as_tensor(avoid.compute_qp_inequalities(cfg, dt).h)
 print(f"20-step loop with collision avoidance: {1e3 * wall:.2f} ms for the batch "
       f"({float(res['iters'].double().mean()):.1f} solves per problem); collision rows within the detection distance "

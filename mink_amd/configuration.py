@@ -134,11 +134,51 @@ class Configuration:
         b = int(bad[0, 0])
         self._report_limit_violation(b, int(first[b]), bad.shape[0], safety_break)
 
-    # ---- deferred reports of the batched, asynchronous calls ---------------------
+    # ---- reports of the batched calls -----------------------------------------------
+    # By default a batched solve_ik / solve_ik_iterate / move_to keeps the reference's contract:
+    # the limit warning and the assert on a failed QP happen inside the call (which therefore
+    # waits for the device).  Inside `with configuration.deferred_checks():` (or with
+    # `configuration.defer_checks = True`) the calls queue their work and return at once; the
+    # reports accumulate on the device and `check()` -- called explicitly, or on leaving the
+    # `with` block -- delivers them.
+    defer_checks = False
+
+    def deferred_checks(self):
+        """Context manager: batched calls inside it do not wait for the device; their limit
+        warnings and solver failures are reported when the block ends (or by `check()`)."""
+        cfg = self
+
+        class _Deferred:
+            def __enter__(self_inner):
+                self_inner.saved = cfg.defer_checks
+                cfg.defer_checks = True
+                return cfg
+
+            def __exit__(self_inner, exc_type, exc, tb):
+                cfg.defer_checks = self_inner.saved
+                if exc_type is None:
+                    cfg.check()
+                return False
+
+        return _Deferred()
+
     def _defer_limit_check(self, tol: float = 1e-6) -> None:
         """Queue the limit check on the stream and keep its result on the device; nothing
-        waits for it.  `check()` turns the latest one into the reference's warning."""
-        self._pending_first = self.dmodel.first_limit_violation(self._q, tol)
+        waits for it.  Per configuration the earliest violation since the last `check()` is
+        kept, which `check()` turns into the reference's warning."""
+        first = self.dmodel.first_limit_violation(self._q, tol)
+        acc = getattr(self, "_pending_first", None)
+        self._pending_first = first if acc is None or acc.shape != first.shape else torch.where(acc >= 0, acc, first)
+
+    def _report_status(self, status: torch.Tensor) -> None:
+        """The reference's `assert dq is not None` (mink/solve_ik.py:103) for a batch: now, or
+        folded into the deferred reports."""
+        if self.defer_checks:
+            self._defer_status(status)
+            return
+        n_bad = int((status != 0).sum())
+        assert n_bad == 0, (f"QP solver failed for {n_bad} of {status.shape[0]} problems (infeasible limits or "
+                            f"non-finite input); worst status {int(status.max())}")
 
     def _defer_status(self, status: torch.Tensor) -> None:
         """Fold the solver status of a batched call into a running per-problem maximum on
@@ -149,9 +189,9 @@ class Configuration:
 
     def check(self) -> None:
         """Wait for the batched calls issued so far and report what they deferred: a warning
-        for the limit check of the last `solve_ik(..., safety_break=False)` (the reference's
-        logging.warning, mink/configuration.py:107-110) and an AssertionError if any QP since
-        the last `check()` failed (the reference's assert, mink/solve_ik.py:103)."""
+        for the limit checks of `solve_ik(..., safety_break=False)` since the last `check()`
+        (the reference's logging.warning, mink/configuration.py:107-110) and an AssertionError
+        if any QP since then failed (the reference's assert, mink/solve_ik.py:103)."""
         first = getattr(self, "_pending_first", None)
         self._pending_first = None
         if first is not None and first.shape[0] == self.batch_size:

@@ -6,9 +6,9 @@ from typing import Mapping, NamedTuple, Optional, Sequence
 import numpy as np
 
 from . import _lib as L
-from .constants import dof_width
+from .constants import dof_width, qpos_width
 from .exceptions import LimitDefinitionError
-from .mjcf import JNT_FREE, MJ_MAXVAL
+from .mjcf import JNT_BALL, JNT_FREE, MJ_MAXVAL
 
 
 class Constraint(NamedTuple):
@@ -62,8 +62,9 @@ class ConfigurationLimit(Limit):
             if jt == JNT_FREE or not model.jnt_limited[jnt]:
                 continue
             padr = model.jnt_qposadr[jnt]
-            lower[padr] = model.jnt_range[jnt, 0] + min_distance_from_limits
-            upper[padr] = model.jnt_range[jnt, 1] - min_distance_from_limits
+            qdim = qpos_width(jt)      # a ball joint fills its four quaternion slots
+            lower[padr:padr + qdim] = model.jnt_range[jnt, 0] + min_distance_from_limits
+            upper[padr:padr + qdim] = model.jnt_range[jnt, 1] - min_distance_from_limits
             vadr = model.jnt_dofadr[jnt]
             index_list.extend(range(vadr, vadr + dof_width(jt)))
         self.indices = np.array(index_list, dtype=np.int64)
@@ -77,32 +78,57 @@ class ConfigurationLimit(Limit):
         # overwrites lower / upper afterwards (the reference reads them at every call,
         # mink/limits/configuration_limit.py:69-124) is served by the generic route instead
         self._built_bounds = (lower.copy(), upper.copy())
-        self._index_qadr = np.array([q for j in range(model.njnt)
-                                     if int(model.jnt_type[j]) != JNT_FREE and model.jnt_limited[j]
-                                     for q in range(model.jnt_qposadr[j], model.jnt_qposadr[j] + dof_width(int(model.jnt_type[j])))],
-                                    dtype=np.int64)
+        self._limited_joints = [j for j in range(model.njnt)
+                                if int(model.jnt_type[j]) != JNT_FREE and model.jnt_limited[j]]
+        # A limited ball joint has no per-dof range: the reference differences the configuration
+        # with `upper` / `lower` read as quaternions (mink/limits/configuration_limit.py:98-119);
+        # the kernels do not carry that, the generic route below does.
+        self._has_limited_ball = any(int(model.jnt_type[j]) == JNT_BALL for j in self._limited_joints)
 
     def _overridden(self) -> bool:
         return not (np.array_equal(self.lower, self._built_bounds[0]) and np.array_equal(self.upper, self._built_bounds[1]))
 
     def _is_custom(self) -> bool:
-        return self._overridden()
+        return self._overridden() or self._has_limited_ball
+
+    def _difference(self, q, bound):
+        """(bound (-) q) on the limited dofs, i.e. mj_differentiatePos(dt = 1, qpos1 = q,
+        qpos2 = bound)[indices] for q [B, nq]: plain differences for hinge / slide joints, and for
+        a ball joint the rotation vector of conj(q) * bound (mju_subQuat: quaternions as given,
+        not normalised; angle wrapped to (-pi, pi])."""
+        import torch
+        m = self.model
+        cols = []
+        for j in self._limited_joints:
+            a = int(m.jnt_qposadr[j])
+            if int(m.jnt_type[j]) != JNT_BALL:
+                cols.append((bound[a] - q[:, a])[:, None])
+                continue
+            qa, qb = bound[a:a + 4][None, :], q[:, a:a + 4] * torch.tensor([1.0, -1.0, -1.0, -1.0], dtype=q.dtype, device=q.device)
+            # d = conj(q) * bound
+            w = qb[:, 0] * qa[:, 0] - (qb[:, 1:] * qa[:, 1:]).sum(dim=1)
+            xyz = qb[:, :1] * qa[:, 1:] + qa[:, :1] * qb[:, 1:] + torch.linalg.cross(qb[:, 1:], qa[:, 1:].expand_as(qb[:, 1:]))
+            n = xyz.norm(dim=1)
+            axis = torch.where((n < 1e-15)[:, None], torch.tensor([1.0, 0.0, 0.0], dtype=q.dtype, device=q.device), xyz / n.clamp_min(1e-300)[:, None])
+            angle = 2.0 * torch.atan2(n, w)
+            angle = torch.where(angle > np.pi, angle - 2.0 * np.pi, angle)
+            cols.append(axis * angle[:, None])
+        return torch.cat(cols, dim=1)
 
     def compute_qp_inequalities(self, configuration, dt: float) -> Constraint:
-        if not self._overridden():
+        if not self._is_custom():
             return super().compute_qp_inequalities(configuration, dt)
         if self.projection_matrix is None:
             return Constraint()
         import torch
-        if any(int(t) == 1 for t in self.model.jnt_type[self.model.jnt_limited != 0]):
-            raise LimitDefinitionError("overridden bounds are supported for hinge and slide joints only")
-        q = configuration.q_tensor[:, self._index_qadr]
-        lo = torch.as_tensor(np.asarray(self.lower)[self._index_qadr], dtype=torch.float64).to(q.device)
-        hi = torch.as_tensor(np.asarray(self.upper)[self._index_qadr], dtype=torch.float64).to(q.device)
+        q = configuration.q_tensor
+        lo = torch.as_tensor(np.asarray(self.lower), dtype=torch.float64).to(q.device)
+        hi = torch.as_tensor(np.asarray(self.upper), dtype=torch.float64).to(q.device)
         P = torch.as_tensor(self.projection_matrix, dtype=torch.float64).to(q.device)
         B = q.shape[0]
         G = torch.cat([P, -P], dim=0)[None].expand(B, -1, -1).contiguous()
-        h = torch.cat([self.gain * (hi[None] - q), self.gain * (q - lo[None])], dim=1)
+        # h = gain * [(upper (-) q); -(lower (-) q)]   (mink/limits/configuration_limit.py:98-124)
+        h = torch.cat([self.gain * self._difference(q, hi), -self.gain * self._difference(q, lo)], dim=1)
         return Constraint(G=configuration._out(G), h=configuration._out(h))
 
     def _key(self, model):

@@ -102,7 +102,7 @@ def move_to(configuration, frame_task, tasks: Sequence, target_pos, target_rot: 
                 goals = goals[None, :].expand(B, -1)
             res = prob.move_to_(configuration.q_tensor, goals.contiguous(), cfg, dt, damping, max_steps, max_iters,
                                 pos_threshold, ori_threshold)
-            configuration._defer_status(res["status"])      # reported by configuration.check()
+            configuration._report_status(res["status"])     # the reference's assert on a failed QP
             return dict(steps=res["steps"], reached=res["reached"].bool(), solves=res["solves"].to(torch.int64))
     return _move_to_stepwise(configuration, frame_task, tasks, target_pos, target_rot, cfg, dt, solver, damping,
                              max_steps, max_iters, pos_threshold, ori_threshold, limits)

@@ -91,9 +91,9 @@ def build_ik(configuration, tasks: Sequence[Task], dt: float, damping: float = 1
 
 
 def _limit_check(configuration, safety_break: bool) -> None:
-    """mink/solve_ik.py:99.  A single configuration, or a caller that wants the exception,
-    gets the answer now; a batch with safety_break=False only queues the check."""
-    if safety_break or not configuration.batched:
+    """mink/solve_ik.py:99.  The answer comes now, as in the reference, unless the caller has
+    opted into deferred reports (Configuration.deferred_checks) and does not want the exception."""
+    if safety_break or not configuration.batched or not configuration.defer_checks:
         configuration.check_limits(safety_break=safety_break)
     else:
         configuration._defer_limit_check()
@@ -110,10 +110,12 @@ def solve_ik(configuration, tasks: Sequence[Task], dt: float, solver: str, dampi
     """Velocity ``v`` tangent to the current configuration(s): [nv] numpy for a single
     configuration, [B, nv] device tensor for a batch.
 
-    For a batch the call is asynchronous on the current stream and never waits for the
-    device: the limit warning (``safety_break=False``) and the solver's per-problem status are
-    kept on the device and reported by ``configuration.check()``; ``safety_break=True`` asks
-    for the exception and therefore waits for the limit check."""
+    As in the reference (mink/solve_ik.py:99-103) the limit check and the assert on a failed QP
+    happen inside the call, for a batch too -- any failing problem fails the call.  A caller that
+    wants a batched call to return without waiting for the device wraps it in
+    ``with configuration.deferred_checks():``; the limit warning and the solver's per-problem
+    status are then kept on the device and reported when the block ends (``safety_break=True``
+    still raises at once)."""
     _check_solver(solver)
     limits = _resolve_limits(configuration, limits)
     if _has_custom(tasks, limits):
@@ -124,7 +126,7 @@ def solve_ik(configuration, tasks: Sequence[Task], dt: float, solver: str, dampi
         P, c, G, h = _assemble_with_custom(configuration, tasks, limits, dt, damping)
         x, status = qp_solve(P, c, G, h)
         if configuration.batched:
-            configuration._defer_status(status)
+            configuration._report_status(status)
         else:
             assert int((status != 0).sum()) == 0, "QP solver failed (infeasible limits or non-finite input)"
         return configuration._out(x / dt)
@@ -137,12 +139,12 @@ def solve_ik(configuration, tasks: Sequence[Task], dt: float, solver: str, dampi
             configuration._report_limit_violation(0, first, 1, safety_break)
         assert status == 0, "QP solver failed (infeasible limits or non-finite input)"
         return v
-    # A batch: nothing here waits for the device.  The limit check (unless the caller asked for
-    # the exception) and the solver status stay on the device until `configuration.check()`.
+    # A batch: limit check, solve, and the assert on the solver status (deferred when the caller
+    # asked for that).
     _limit_check(configuration, safety_break)
     prob, targets = get_problem(configuration, tasks, _resolve_limits(configuration, limits))
     v, status = prob.solve(configuration.q_tensor, targets, dt, damping)
-    configuration._defer_status(status)
+    configuration._report_status(status)
     return v
 
 
@@ -168,6 +170,6 @@ def solve_ik_iterate(configuration, tasks: Sequence[Task], dt: float, solver: st
         return res
     res = prob.iterate_(configuration.q_tensor, targets, dt, damping, max_iters, pos_threshold, ori_threshold,
                         want_v=True)
-    configuration._defer_status(res["status"])     # also returned: callers may look at it themselves
+    configuration._report_status(res["status"])     # also returned: callers may look at it themselves
     return dict(res)
 

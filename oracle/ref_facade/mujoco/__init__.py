@@ -52,6 +52,10 @@ class MjModel:
     def from_xml_path(cls, path):
         return cls(_mjcf.load_mjcf(path))
 
+    @classmethod
+    def from_xml_string(cls, xml):
+        return cls(_mjcf.load_mjcf_string(xml))
+
     def __getattr__(self, k):
         return getattr(self._t, k)
 

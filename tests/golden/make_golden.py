@@ -10,7 +10,7 @@ mink/solve_ik.py -- and NOT MuJoCo or quadprog.
 Run from the repository root:  python tests/golden/make_golden.py
 Outputs (inputs + expected outputs only, no reference source):
   lie.npz, tidybot_build_ik.npz, tidybot_loop.npz, mobile_kinova_build_ik.npz,
-  collision.npz, api_strings.json
+  collision.npz, api_strings.json, limited_ball.npz
 """
 import json
 import os
@@ -337,10 +337,36 @@ def make_api_strings():
     print("api_strings.json", len(cases))
 
 
+def make_limited_ball():
+    """ConfigurationLimit of the reference on a model with a LIMITED ball joint: the constructor's
+    arrays (qpos_dim slots per joint, mink/limits/configuration_limit.py:46-53) and the rows at a
+    few configurations."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ref_models
+    rng = np.random.default_rng(13)
+    model = mujoco.MjModel.from_xml_string(ref_models.LIMITED_BALL_AND_HINGE)
+    limit = mink.ConfigurationLimit(model, gain=0.9, min_distance_from_limits=0.05)
+    out = dict(lower=limit.lower, upper=limit.upper, indices=np.asarray(limit.indices),
+               projection_matrix=limit.projection_matrix, gain=0.9, min_distance_from_limits=0.05, dt=0.01)
+    qs, Gs, hs = [], [], []
+    for _ in range(12):
+        q = np.concatenate([random_unit_quat(rng), rng.uniform(-0.4, 1.4, 1)])
+        cfg = mink.Configuration(model, q)
+        con = limit.compute_qp_inequalities(cfg, 0.01)
+        qs.append(q); Gs.append(con.G); hs.append(con.h)
+    out.update(q=np.array(qs), G=np.array(Gs), h=np.array(hs))
+    np.savez(os.path.join(HERE, "limited_ball.npz"), **out)
+    print("limited_ball.npz", out["h"].shape)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "limited_ball":
+        make_limited_ball()
+        sys.exit(0)
     make_lie()
     make_build_ik("cube.xml", "tidybot_build_ik.npz", with_extras=True)
     make_build_ik("scene_mobile_kinova.xml", "mobile_kinova_build_ik.npz", with_extras=False)
     make_loop()
     make_collision()
     make_api_strings()
+    make_limited_ball()

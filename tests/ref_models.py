@@ -93,3 +93,23 @@ SUBTREES = """
   </worldbody>
 </mujoco>
 """
+
+# Not from the reference's tests: a LIMITED ball joint (and a limited hinge behind it), the one
+# joint kind for which ConfigurationLimit fills more than one qpos slot per joint
+# (mink/limits/configuration_limit.py:46-53).
+LIMITED_BALL_AND_HINGE = """
+<mujoco>
+  <compiler angle="radian"/>
+  <worldbody>
+    <body>
+      <joint type="ball" name="ball" limited="true" range="0 0.9"/>
+      <geom type="sphere" size=".1" mass=".1"/>
+      <body pos="0 0 0.3">
+        <joint type="hinge" name="hinge" axis="0 1 0" range="-0.5 1.57" limited="true"/>
+        <geom type="sphere" size=".1" mass=".1"/>
+        <site name="tip" pos="0 0 0.2"/>
+      </body>
+    </body>
+  </worldbody>
+</mujoco>
+"""

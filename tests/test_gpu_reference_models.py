@@ -116,13 +116,22 @@ def test_zero_damping_on_a_dof_without_cost_is_reported():
     cfg = mink.Configuration(model, q)
     task = mink.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=0.0)
     task.set_target_from_configuration(cfg)
-    v = mink.solve_ik(cfg, [task], 0.005, "quadprog", 0.0, limits=[])
+    # as in the reference, the call itself fails ...
     with pytest.raises(AssertionError):
-        cfg.check()
-    assert float(v.abs().max()) == 0.0
+        mink.solve_ik(cfg, [task], 0.005, "quadprog", 0.0, limits=[])
+    # ... unless the caller defers the reports of its batched calls: then nothing waits for the
+    # device, and the failure surfaces at the end of the block (or at an explicit check())
+    with pytest.raises(AssertionError):
+        with cfg.deferred_checks():
+            v = mink.solve_ik(cfg, [task], 0.005, "quadprog", 0.0, limits=[])
+            assert float(v.abs().max()) == 0.0
+            v2 = mink.solve_ik(cfg, [task], 0.005, "quadprog", 1e-12, limits=[])     # a good call does not clear it
+    assert float(v2.abs().max()) <= 1e-9
     v = mink.solve_ik(cfg, [task], 0.005, "quadprog", 1e-12, limits=[])
-    cfg.check()
     assert float(v.abs().max()) <= 1e-9
+    with cfg.deferred_checks():
+        v = mink.solve_ik(cfg, [task], 0.005, "quadprog", 1e-12, limits=[])
+    assert cfg.defer_checks is False
 
 
 def test_posture_target_update_keeps_the_problem():
@@ -146,7 +155,6 @@ def test_posture_target_update_keeps_the_problem():
             target = W.sample_q(model, rng, 1)[0]
             ptask.set_target(target)
             v = mink.solve_ik(cfg, [ftask, ptask] + extra, 0.005, "quadprog", 1e-3).cpu().numpy()
-            cfg.check()
             n_now = len(cfg.dmodel.problem_cache)
             assert n_before is None or n_now == n_before, "a changed posture target must not create a new problem"
             n_before = n_now
@@ -159,3 +167,35 @@ def test_posture_target_update_keeps_the_problem():
                     ot.append(o.ComTask(cost=np.full(3, 0.1), target_com=np.asarray(extra[0].target_com).reshape(-1, 3)[b]))
                 vr = o.solve_ik(ocfg, ot, 0.005, damping=1e-3, limits=[o.ConfigurationLimit(model)])
                 np.testing.assert_allclose(v[b], vr, rtol=0, atol=1e-8)
+
+
+def test_limited_ball_joint_rows_and_solve(golden_dir):
+    """A LIMITED ball joint: the rows of ConfigurationLimit against the reference's
+    (golden limited_ball.npz: mink/limits/configuration_limit.py:69-124 differences the
+    configuration with `upper` / `lower` read as quaternions), and solve_ik with that limit
+    against the oracle."""
+    import os
+    g = np.load(os.path.join(golden_dir, "limited_ball.npz"))
+    model = mink.load_mjcf_string(R.LIMITED_BALL_AND_HINGE)
+    limit = mink.ConfigurationLimit(model, gain=float(g["gain"]), min_distance_from_limits=float(g["min_distance_from_limits"]))
+    cfg = mink.Configuration(model, g["q"])
+    con = limit.compute_qp_inequalities(cfg, float(g["dt"]))
+    np.testing.assert_allclose(torch.as_tensor(con.G).cpu().numpy(), g["G"], rtol=0, atol=0)
+    np.testing.assert_allclose(torch.as_tensor(con.h).cpu().numpy(), g["h"], rtol=0, atol=1e-13)
+    # solve_ik with the limit (generic route: rows from the host mirror, QP by mk_qp_solve_batch)
+    task = mink.FrameTask("tip", "site", 1.0, 1.0, lm_damping=1.0)
+    rng = np.random.default_rng(3)
+    tg = np.array([np.concatenate([rq / np.linalg.norm(rq), rng.uniform(-0.3, 0.3, 3)])
+                   for rq in rng.normal(size=(len(g["q"]), 4))])
+    task.set_target(mink.SE3(torch.tensor(tg, device="cuda:0")))
+    v = mink.solve_ik(cfg, [task], 0.01, "quadprog", 1e-3, limits=[limit]).cpu().numpy()
+    for b in range(len(g["q"])):
+        ocfg = o.Configuration(model, g["q"][b])
+        ot = [o.FrameTask("tip", "site", 1.0, 1.0, lm_damping=1.0, target=tg[b])]
+        ol = o.ConfigurationLimit(model, gain=float(g["gain"]), min_distance_from_limits=float(g["min_distance_from_limits"]))
+        P, c, G, h = o.build_ik(ocfg, ot, 0.01, 1e-3, [ol])
+        np.testing.assert_allclose(G, g["G"][b], rtol=0, atol=0)
+        np.testing.assert_allclose(h, g["h"][b], rtol=0, atol=1e-13)
+        x, status, _, _ = o.solve_qp(P, c, G, h)
+        if status == 0:
+            np.testing.assert_allclose(v[b], x / 0.01, rtol=0, atol=1e-8)

@@ -67,3 +67,18 @@ def test_mocap_model_tables():
     assert model.nmocap == 1 and model.body_mocapid[model.body_id("mocap")] == 0
     np.testing.assert_allclose(model.body_quat[model.body_id("mocap")], [np.sqrt(0.5), np.sqrt(0.5), 0, 0])
     np.testing.assert_allclose(model.qpos0[:7], [0.1, -0.1, 0, 1, 0, 0, 0])
+
+
+def test_limited_ball_joint_fills_every_quaternion_slot(golden_dir):
+    """ConfigurationLimit on a LIMITED ball joint against the reference's own constructor
+    (golden from mink/limits/configuration_limit.py:41-62): lower / upper carry the range in all
+    four qpos slots of the joint, and the three dofs are limited."""
+    import os
+    g = np.load(os.path.join(golden_dir, "limited_ball.npz"))
+    model = load_mjcf_string(R.LIMITED_BALL_AND_HINGE)
+    assert model.nq == 5 and model.nv == 4 and int(model.jnt_type[0]) == JNT_BALL
+    limit = ConfigurationLimit(model, gain=float(g["gain"]), min_distance_from_limits=float(g["min_distance_from_limits"]))
+    np.testing.assert_array_equal(limit.lower, g["lower"])
+    np.testing.assert_array_equal(limit.upper, g["upper"])
+    np.testing.assert_array_equal(limit.indices, g["indices"])
+    np.testing.assert_array_equal(limit.projection_matrix, g["projection_matrix"])
