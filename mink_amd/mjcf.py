@@ -74,6 +74,38 @@ def _quat_to_mat(q) -> np.ndarray:
                      [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z]])
 
 
+def _z_to_quat(vec) -> np.ndarray:
+    """Quaternion of the smallest rotation that takes the z axis to `vec` (what the MuJoCo
+    compiler uses for `zaxis` and `fromto`): axis z x vec, angle atan2(|z x vec|, vec_z); a
+    vector along -z turns about x."""
+    v = np.asarray(vec, dtype=np.float64)
+    v = v / np.linalg.norm(v)
+    axis = np.cross([0.0, 0.0, 1.0], v)
+    n = np.linalg.norm(axis)
+    axis = np.array([1.0, 0.0, 0.0]) if n < 1e-10 else axis / n
+    ang = np.arctan2(n, v[2])
+    return np.concatenate([[np.cos(0.5 * ang)], np.sin(0.5 * ang) * axis])
+
+
+def _mat_to_quat(m) -> np.ndarray:
+    """mju_mat2Quat for a rotation matrix (rows m[0..2]), normalised."""
+    m = np.asarray(m, dtype=np.float64)
+    tr = m[0, 0] + m[1, 1] + m[2, 2]
+    if tr > 0:
+        w = 0.5 * np.sqrt(1.0 + tr)
+        q = [w, 0.25 * (m[2, 1] - m[1, 2]) / w, 0.25 * (m[0, 2] - m[2, 0]) / w, 0.25 * (m[1, 0] - m[0, 1]) / w]
+    elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+        x = 0.5 * np.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2])
+        q = [0.25 * (m[2, 1] - m[1, 2]) / x, x, 0.25 * (m[0, 1] + m[1, 0]) / x, 0.25 * (m[0, 2] + m[2, 0]) / x]
+    elif m[1, 1] > m[2, 2]:
+        y = 0.5 * np.sqrt(1.0 - m[0, 0] + m[1, 1] - m[2, 2])
+        q = [0.25 * (m[0, 2] - m[2, 0]) / y, 0.25 * (m[0, 1] + m[1, 0]) / y, y, 0.25 * (m[1, 2] + m[2, 1]) / y]
+    else:
+        z = 0.5 * np.sqrt(1.0 - m[0, 0] - m[1, 1] + m[2, 2])
+        q = [0.25 * (m[1, 0] - m[0, 1]) / z, 0.25 * (m[0, 2] + m[2, 0]) / z, 0.25 * (m[1, 2] + m[2, 1]) / z, z]
+    return _normalize_quat(q)
+
+
 def _axisangle_quat(axis, angle: float) -> np.ndarray:
     axis = np.asarray(axis, dtype=np.float64)
     n = np.linalg.norm(axis)
@@ -398,9 +430,16 @@ class _Compiler:
         if "axisangle" in a:
             v = _floats(a["axisangle"])
             return _axisangle_quat(v[:3], v[3] * self.angle_scale)
-        for unsupported in ("xyaxes", "zaxis"):
-            if unsupported in a:
-                raise NotImplementedError(f"orientation attribute '{unsupported}'")
+        if "xyaxes" in a:
+            # x axis as given, y made orthogonal to it, z = x cross y; the frame's axes are the
+            # columns of its rotation matrix
+            v = _floats(a["xyaxes"])
+            x = np.array(v[:3]) / np.linalg.norm(v[:3])
+            y = np.array(v[3:6]) - np.dot(x, v[3:6]) * x
+            y = y / np.linalg.norm(y)
+            return _mat_to_quat(np.column_stack([x, y, np.cross(x, y)]))
+        if "zaxis" in a:
+            return _z_to_quat(_floats(a["zaxis"]))
         return np.array([1.0, 0.0, 0.0, 0.0])
 
     def _visit_body(self, elem: ET.Element, parent_id: int, childclass: str) -> None:
@@ -476,15 +515,26 @@ class _Compiler:
                     gtype = GEOM_MESH if "mesh" in a else GEOM_SPHERE
                 size = _floats(a.get("size", "0 0 0"))
                 size = (size + [0.0, 0.0, 0.0])[:3]
+                gpos = np.array(_floats(a.get("pos", "0 0 0")))
+                gquat = self._orientation(a)
                 if "fromto" in a:
-                    raise NotImplementedError("geom fromto")
+                    # a segment instead of pos / quat / length: centre at its midpoint, z axis along
+                    # from - to, half-length in the size slot of the geom's long axis (capsule,
+                    # cylinder: size[1]; box, ellipsoid: size[2])
+                    if gtype not in (GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, GEOM_ELLIPSOID):
+                        raise ValueError("fromto needs a capsule, cylinder, box or ellipsoid geom")
+                    ft = np.array(_floats(a["fromto"]))
+                    vec = ft[:3] - ft[3:]
+                    size[1 if gtype in (GEOM_CAPSULE, GEOM_CYLINDER) else 2] = 0.5 * float(np.linalg.norm(vec))
+                    gpos = 0.5 * (ft[:3] + ft[3:])
+                    gquat = _z_to_quat(vec)
                 self.geoms_by_body[bid].append({
                     "name": a.get("name", ""),
                     "body": bid,
                     "type": gtype,
                     "size": np.array(size),
-                    "pos": np.array(_floats(a.get("pos", "0 0 0"))),
-                    "quat": self._orientation(a),
+                    "pos": gpos,
+                    "quat": gquat,
                     "contype": int(a.get("contype", "1")),
                     "conaffinity": int(a.get("conaffinity", "1")),
                     "mass": float(a["mass"]) if "mass" in a else None,

@@ -1,7 +1,8 @@
 """Task Jacobians of the device code against finite differences of the device code's own
 errors: the cases of the reference's tests/test_jacobians.py (every task type, J = de/dq along
 mj_integratePos steps of 1e-6, same tolerances), on the floating-base tree of the test models
-(free + ball + hinge + slide joints, where the reference uses a humanoid) and on TidyBot.
+(free + ball + hinge + slide joints), on the humanoid-shaped tree tests/models/biped.xml (a free
+joint, two six-hinge legs, two arms: the shape of the reference's G1 model) and on TidyBot.
 The nv + 1 configurations of one check are evaluated as one batch by mk_task_eval_batch."""
 import os
 
@@ -72,17 +73,25 @@ def tidybot():
     return load_builtin("tidybot_cube")
 
 
-def test_frame_task(fmodel, tidybot):
+@pytest.fixture(scope="module")
+def biped():
+    return load_mjcf(os.path.join(HERE, "models", "biped.xml"))
+
+
+def test_frame_task(fmodel, tidybot, biped):
     rng = np.random.default_rng(42)
-    for model, name, ftype in ((fmodel, "tool", "site"), (fmodel, "fore", "body"), (tidybot, "pinch_site", "site")):
+    for model, name, ftype in ((fmodel, "tool", "site"), (fmodel, "fore", "body"), (tidybot, "pinch_site", "site"),
+                               (biped, "l_foot_site", "site"), (biped, "r_hand", "site"), (biped, "head", "site"),
+                               (biped, "r_sole", "geom")):
         task = mink.FrameTask(frame_name=name, frame_type=ftype, position_cost=1.0, orientation_cost=1.0)
         task.set_target(mink.SE3.sample_uniform(generator=torch.Generator().manual_seed(7)))
         check_jacobian_finite_diff(model, task, 1e-5, rng)
 
 
-def test_relative_frame_task(fmodel, tidybot):
+def test_relative_frame_task(fmodel, tidybot, biped):
     rng = np.random.default_rng(43)
-    cases = ((fmodel, "tool", "site", "torso", "body"), (tidybot, "pinch_site", "site", "base_link", "body"))
+    cases = ((fmodel, "tool", "site", "torso", "body"), (tidybot, "pinch_site", "site", "base_link", "body"),
+             (biped, "r_hand", "site", "l_foot", "body"), (biped, "l_foot_site", "site", "r_foot_site", "site"))
     for model, name, ftype, root, rtype in cases:
         task = mink.RelativeFrameTask(frame_name=name, frame_type=ftype, root_name=root, root_type=rtype,
                                       position_cost=1.0, orientation_cost=1.0)
@@ -90,24 +99,24 @@ def test_relative_frame_task(fmodel, tidybot):
         check_jacobian_finite_diff(model, task, 1e-5, rng)
 
 
-def test_posture_task(fmodel, tidybot):
+def test_posture_task(fmodel, tidybot, biped):
     rng = np.random.default_rng(44)
-    for model in (fmodel, tidybot):
+    for model in (fmodel, tidybot, biped):
         task = mink.PostureTask(model=model, cost=1.0)
         target = mink.Configuration(model, model.qpos0).integrate(rng.normal(size=model.nv) * 1e-3, 1.0)
         task.set_target(target)
         check_jacobian_finite_diff(model, task, 1e-6, rng, ball_from=np.asarray(target))
 
 
-def test_com_task(fmodel, tidybot):
+def test_com_task(fmodel, tidybot, biped):
     rng = np.random.default_rng(45)
-    for model in (fmodel, tidybot):
+    for model in (fmodel, tidybot, biped):
         task = mink.ComTask(cost=1.0)
         task.set_target(np.zeros(3))
         check_jacobian_finite_diff(model, task, 1e-6, rng)
 
 
-def test_damping_task(fmodel, tidybot):
+def test_damping_task(fmodel, tidybot, biped):
     rng = np.random.default_rng(46)
-    for model in (fmodel, tidybot):
+    for model in (fmodel, tidybot, biped):
         check_jacobian_finite_diff(model, mink.DampingTask(model, cost=1.0), 1e-6, rng, ball_from=model.qpos0)

@@ -43,6 +43,57 @@ def random_q(model, rng):
 FRAMES = [("site", "tool"), ("body", "fore"), ("geom", "leg_geom"), ("body", "ball_obj")]
 
 
+@pytest.fixture(scope="module")
+def biped():
+    """Humanoid-shaped tree (free joint, two six-hinge legs, two arms, fromto capsules)."""
+    return load_mjcf(os.path.join(HERE, "models", "biped.xml"))
+
+
+BIPED_FRAMES = [("site", "l_foot_site"), ("site", "r_hand"), ("geom", "l_fist"), ("body", "r_shin")]
+
+
+@pytest.mark.parametrize("ftype,fname", BIPED_FRAMES)
+def test_biped_frame_jacobian_is_the_derivative_of_the_pose(biped, ftype, fname):
+    """The same first-order property on the multi-branch floating-base tree."""
+    rng = np.random.default_rng(10)
+    eps = 1e-6
+    for _ in range(2):
+        q = random_q(biped, rng)
+        cfg = o.Configuration(biped, q)
+        J = cfg.get_frame_jacobian(fname, ftype)
+        T0 = cfg.get_transform_frame_to_world(fname, ftype)
+        for i in range(biped.nv):
+            dv = np.zeros(biped.nv)
+            dv[i] = 1.0
+            qp, qm = q.copy(), q.copy()
+            mj.mj_integratePos(biped, qp, dv, eps)
+            mj.mj_integratePos(biped, qm, dv, -eps)
+            Tp = o.Configuration(biped, qp).get_transform_frame_to_world(fname, ftype)
+            Tm = o.Configuration(biped, qm).get_transform_frame_to_world(fname, ftype)
+            fd = (o.se3_log(o.se3_multiply(o.se3_inverse(T0), Tp)) - o.se3_log(o.se3_multiply(o.se3_inverse(T0), Tm))) / (2 * eps)
+            np.testing.assert_allclose(J[:, i], fd, rtol=0, atol=2e-8)
+    # a dof of the other leg does not move this frame
+    if fname == "l_foot_site":
+        r = int(biped.jnt_dofadr[biped.joint_id("r_knee")])
+        assert np.all(J[:, r] == 0.0)
+
+
+def test_biped_com_jacobian_is_the_derivative_of_the_com(biped):
+    rng = np.random.default_rng(12)
+    eps = 1e-6
+    task = o.ComTask(cost=np.ones(3), target_com=np.zeros(3))
+    q = random_q(biped, rng)
+    J = task.jacobian(o.Configuration(biped, q))
+    for i in range(biped.nv):
+        dv = np.zeros(biped.nv)
+        dv[i] = 1.0
+        qp, qm = q.copy(), q.copy()
+        mj.mj_integratePos(biped, qp, dv, eps)
+        mj.mj_integratePos(biped, qm, dv, -eps)
+        fd = (task.error(o.Configuration(biped, qp)) - task.error(o.Configuration(biped, qm))) / (2 * eps)
+        np.testing.assert_allclose(J[:, i], fd, rtol=0, atol=1e-8)
+
+
 @pytest.mark.parametrize("ftype,fname", FRAMES)
 def test_frame_jacobian_is_the_derivative_of_the_pose(fmodel, ftype, fname):
     """T(q (+) eps e_i) = T(q) exp(eps J_i) to first order (tests/test_jacobians.py of the
@@ -333,3 +384,70 @@ def test_gpu_primitive_collision_rows_vs_oracle(fmodel):
         np.testing.assert_allclose(G[b], Go, rtol=0, atol=1e-9)
         active += int(fin.sum())
     assert active > 100
+
+
+@pytest.mark.gpu
+def test_gpu_biped_solve_ik_vs_oracle(biped):
+    """Whole-body IK of the humanoid-shaped tree on the wave-per-problem kernels: both feet and a
+    hand as frame tasks, the centre of mass, a posture task; joint and velocity limits; one step
+    and a short loop against the oracle."""
+    import torch
+    from mink_amd.engine import DeviceModel, DeviceProblem
+    m = biped
+    dm = DeviceModel(m, "cuda:0")
+    rng = np.random.default_rng(21)
+    B = 40
+    stand = m.key_qpos[0]
+    q = np.array([stand.copy() for _ in range(B)])
+    for b in range(B):      # around the standing pose, inside the joint ranges
+        v0 = rng.normal(size=m.nv) * 0.15
+        mj.mj_integratePos(m, q[b], v0, 1.0)
+    for j in range(1, m.njnt):
+        a = int(m.jnt_qposadr[j])
+        q[:, a] = np.clip(q[:, a], m.jnt_range[j, 0] + 0.02, m.jnt_range[j, 1] - 0.02)
+    dq = torch.tensor(q, device="cuda:0")
+    frames = [("l_foot_site", 1.0, 1.0), ("r_foot_site", 1.0, 1.0), ("l_hand", 0.5, 0.1)]
+    qs = np.array([stand.copy() for _ in range(B)])
+    for b in range(B):
+        mj.mj_integratePos(m, qs[b], rng.normal(size=m.nv) * 0.15, 1.0)
+    tgs = [dm.frame_pose(torch.tensor(qs, device="cuda:0"), 2, m.site_id(n)) for n, _, _ in frames]
+    com_t = torch.tensor(rng.normal(size=(B, 3)) * 0.03 + np.array([0.0, 0.0, 0.85]), device="cuda:0")
+    tasks = [dict(type=L.TASK_FRAME, frame_type=2, frame_id=m.site_id(n), cost=np.array([pc] * 3 + [oc] * 3), gain=1.0,
+                  lm_damping=0.5) for n, pc, oc in frames]
+    tasks += [dict(type=L.TASK_COM, cost=np.array([1.0, 1.0, 0.2]), gain=0.8, lm_damping=0.0),
+              dict(type=L.TASK_POSTURE, cost=np.concatenate([np.zeros(6), np.full(m.nv - 6, 0.05)]), target_q=stand.copy(),
+                   gain=1.0, lm_damping=0.0)]
+    vel = {m.jnt_names[j]: 3.0 for j in range(1, m.njnt)}
+    limits = [dict(type=L.LIMIT_CONFIGURATION, gain=0.9, min_distance_from_limits=0.0),
+              dict(type=L.LIMIT_VELOCITY, index=[int(m.jnt_dofadr[m.joint_id(k)]) for k in vel], vmax=list(vel.values()))]
+    prob = DeviceProblem(dm, tasks, limits)
+    assert not prob.fused
+    tg = torch.cat(tgs + [com_t], dim=1).contiguous()
+    v, st = prob.solve(dq, tg, 0.01, 1e-6)
+    assert int(st.abs().sum()) == 0
+    v = v.cpu().numpy()
+    tgn = tg.cpu().numpy()
+
+    def oracle_sets(b):
+        ot = [o.FrameTask(n, "site", pc, oc, lm_damping=0.5, target=tgn[b, 7 * i:7 * i + 7]) for i, (n, pc, oc) in enumerate(frames)]
+        ot += [o.ComTask(cost=np.array([1.0, 1.0, 0.2]), target_com=tgn[b, 21:24], gain=0.8),
+               o.PostureTask(cost=np.concatenate([np.zeros(6), np.full(m.nv - 6, 0.05)]), target_q=stand.copy())]
+        return ot, [o.ConfigurationLimit(m, gain=0.9), o.VelocityLimit(m, vel)]
+
+    worst = 0.0
+    for b in range(0, B, 2):
+        ot, ol = oracle_sets(b)
+        ref = o.solve_ik(o.Configuration(m, q[b]), ot, 0.01, damping=1e-6, limits=ol)
+        worst = max(worst, float(np.abs(v[b] - ref).max()))
+    print("biped, one step: max |dv| vs oracle =", worst)
+    assert worst <= 1e-7
+    # a five-step loop
+    qi = dq.clone()
+    res = prob.iterate_(qi, tg, 0.01, 1e-6, 5)
+    assert int(res["status"].abs().sum()) == 0
+    for b in range(0, B, 8):
+        ot, ol = oracle_sets(b)
+        cfg = o.Configuration(m, q[b])
+        for _ in range(5):
+            cfg.integrate_inplace(o.solve_ik(cfg, ot, 0.01, damping=1e-6, limits=ol), 0.01)
+        np.testing.assert_allclose(qi[b].cpu().numpy(), cfg.q, rtol=0, atol=1e-8)
