@@ -390,6 +390,25 @@ def other_workloads(model, dm, prob, q0, targets, out, device, barrier):
             "note": "kinematic part of the reference's move_to (waypoint generator + <=20-iteration IK loop per "
                     "step, default ConfigurationLimit) as one launch (mk_move_to_batch), physics excluded; the "
                     "launch lasts as long as its slowest rollout (max_solves_per_rollout sequential solves)"}
+    # the headline workload in float32 arithmetic (option "f32"; q, targets and v stay float64 in HBM): a
+    # secondary figure with its deviation from the float64 run, never the headline
+    Bf = q0.shape[0]
+    qf = [q0.clone() for _ in range(3)]
+    with L.options(f32=1):
+        wf, ef = time_launches(lambda i: prob.iterate_(qf[i], targets, W.DT, W.DAMPING, ITERS, -1.0, -1.0, out=out), 2, 1, barrier)
+    e32 = out["err"].clone()
+    st32 = int((out["status"] != 0).sum().item())
+    q64 = q0.clone()
+    with L.options(coop=0):
+        prob.iterate_(q64, targets, W.DT, W.DAMPING, ITERS, -1.0, -1.0, out=out)
+    extra["f32_mode_headline_workload"] = {
+        "dtype": "f32", "solves_per_s": Bf * ITERS * 2 / wf, "ms_per_launch": 1e3 * ef / 2, "problems": Bf, "iterations": ITERS,
+        "solver_status_nonzero": st32,
+        "max_abs_dq_vs_f64_after_the_loop": float((qf[-1] - q64).abs().max().item()),
+        "max_abs_d_err_norm_vs_f64": float((e32.norm(dim=1) - out["err"].norm(dim=1)).abs().max().item()),
+        "stated_bound": "single step: |v_f32 - v_f64| <= 1e-3 max(1, |v|_inf) rad/s for problems with a Levenberg-Marquardt "
+                        "term on the frame task (every caller of the reference sets lm_damping = 1); measured 1.6e-4 on this "
+                        "workload (tools/soak_f32.py, tests/test_gpu_f32.py)"}
     return extra
 
 

@@ -23,7 +23,8 @@
  *       0 solved, 1 iteration limit (or an answer of the general solver that fails its final check
  *       of the active rows), 2 infeasible constraints, 3 non-finite input
  *     (a NaN / Inf anywhere in the problem's q row or targets: its velocity is zero and
- *     the iterated entries leave its q as it was; other problems are unaffected).
+ *     the iterated entries leave its q as it was; other problems are unaffected; with option
+ *     "f32" also a Hessian that float32 arithmetic cannot factor).
  *   - quaternions are (w, x, y, z); poses are (qw, qx, qy, qz, x, y, z) like
  *     mink.SE3.wxyz_xyz (mink/lie/se3.py:20-24); twists are (v; omega).
  */
@@ -301,7 +302,17 @@ int mk_lie_op_shape(int32_t op, int32_t* wa, int32_t* wb, int32_t* wo);
 /* Process-wide switches.  No counterpart in the reference (its solver backend is picked by the
  * `solver` string of mink.solve_ik, mink/solve_ik.py:68-77, and has no tuning surface); these
  * choose between equivalent kernel paths and serve the tests and tuning tools.  Every path
- * returns the same results to the stated tolerances, so a caller never needs them.
+ * returns the same results to the stated tolerances, so a caller never needs them -- except
+ * "f32", which trades precision:
+ *   "f32"             0 (default): float64 arithmetic.  1: mk_solve_ik_batch, mk_solve_ik_iterate_batch and
+ *                     mk_move_to_batch run the lane-per-problem kernels of the fused path in float32
+ *                     arithmetic (arrays stay float64).  Bound for problems whose frame task has
+ *                     lm_damping = 1: |v - v_f64|_inf <= 1e-3 max(1, |v|_inf) rad/s per step (measured
+ *                     1.6e-4 on the TidyBot workload); otherwise the error grows like 1e-7 times the
+ *                     condition number of the Hessian, and a factorisation that loses a pivot to rounding
+ *                     gives status 3 with zero velocity.  Problems outside the fused path, or with
+ *                     collision limits or a relative frame task, are refused (MK_ERR_UNSUPPORTED) while
+ *                     the option is set.
  *   "coop"            -1 (default): problems of the fused path with B <= "coop_max_batch" run on the
  *                     cooperative kernels (16 lanes per problem: small batches, the 200 Hz loop of
  *                     interactive_scripts/teleop_mouse.py:99-125); 0 never; 1 always

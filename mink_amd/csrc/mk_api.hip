@@ -29,6 +29,7 @@ struct MkOptionEntry {
 const MkOptionEntry kOptions[MK_OPT_COUNT] = {
     {"staged", 1},        {"lane_rows", 1},     {"general_stage", 1}, {"staged_loop", 1},        {"stream_blocks", -1},
     {"stream_refill", 16}, {"coop", -1},        {"coop_max_batch", 16384}, {"handoff", -1},
+    {"f32", 0},
 };
 std::atomic<long>* option_table() {
   static std::atomic<long> table[MK_OPT_COUNT];
@@ -85,6 +86,20 @@ hipError_t mk_fused_launch_move_to(int nc, const MkFusedDesc* d_desc, int nq, do
                                    double ori_tol, double wp_pos_thr, double wp_pos_step, double wp_rot_thr,
                                    int32_t* steps, int32_t* reached, int32_t* solves, int32_t* status,
                                    hipStream_t stream, int handoff_live, bool* handed);
+
+// ---- the same three in float32 arithmetic (mk_fused32.hip); q, targets and v stay float64 ----
+hipError_t mk_fused32_launch_step(int nc, const MkFusedDesc* d_desc, int nq, const double* q, const double* targets,
+                                  int target_stride, double dt, double damping, int B, double* v, int32_t* status,
+                                  hipStream_t stream);
+hipError_t mk_fused32_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, double* q, const double* targets,
+                                     int target_stride, double dt, double damping, int B, int max_iters,
+                                     double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
+                                     int32_t* status, hipStream_t stream, int handoff_live, bool* handed);
+hipError_t mk_fused32_launch_move_to(int nc, const MkFusedDesc* d_desc, int nq, double* q, const double* goals,
+                                     double dt, double damping, int B, int max_steps, int max_iters, double pos_tol,
+                                     double ori_tol, double wp_pos_thr, double wp_pos_step, double wp_rot_thr,
+                                     int32_t* steps, int32_t* reached, int32_t* solves, int32_t* status,
+                                     hipStream_t stream, int handoff_live, bool* handed);
 
 // ---- implemented in mk_lie.hip ----
 int mk_lie_shape(int op, int* wa, int* wb, int* wo);
@@ -1195,6 +1210,16 @@ static long handoff_threshold(const mk_problem* p) {
   return handoff;
 }
 
+// Option "f32": the fused lane-per-problem kernels in float32 arithmetic.  Only problems the
+// fused path serves without collision rows have such kernels; anything else is refused rather
+// than silently computed in float64.
+static bool want_f32() { return mk_opt(MK_OPT_F32) != 0; }
+static int f32_refusal(const mk_problem* p) {
+  if (p->fused && !p->staged) return MK_OK;
+  return fail(MK_ERR_UNSUPPORTED, "option f32 is set, but float32 kernels exist only for problems of the fused path "
+                                  "without collision limits or relative frame tasks");
+}
+
 int mk_set_option(const char* name, int64_t value) {
   if (!name) return fail(MK_ERR_INVALID, "null option name");
   for (int i = 0; i < MK_OPT_COUNT; ++i)
@@ -1223,6 +1248,12 @@ int mk_solve_ik_batch(const mk_problem* p, const double* d_q, const double* d_ta
   MK_ON_DEVICE(p->model);
   if (!d_q || !d_v || !d_status) return fail(MK_ERR_INVALID, "null argument");
   if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
+  if (want_f32()) {
+    if (int rc = f32_refusal(p); rc != MK_OK) return rc;
+    MK_HIP(mk_fused32_launch_step(p->nc_kernel, p->d_fused, p->info.nq, d_q, d_targets, p->info.target_stride, dt,
+                                  damping, B, d_v, d_status, static_cast<hipStream_t>(stream)));
+    return MK_OK;
+  }
   if (p->staged) {
     // Structured kernel for every problem; it marks the ones with a collision pair that may be
     // within its detection distance.  Those go through the lane-per-problem kernel that builds the
@@ -1272,6 +1303,13 @@ int mk_solve_ik_iterate_batch(const mk_problem* p, double* d_q, const double* d_
   MK_ON_DEVICE(p->model);
   if (!d_q || !d_status) return fail(MK_ERR_INVALID, "null argument");
   if (p->info.target_stride > 0 && !d_targets) return fail(MK_ERR_INVALID, "targets are required");
+  if (want_f32()) {
+    if (int rc = f32_refusal(p); rc != MK_OK) return rc;
+    MK_HIP(mk_fused32_launch_iterate(p->nc_kernel, p->d_fused, p->info.nq, d_q, d_targets, p->info.target_stride, dt,
+                                     damping, B, max_iters, pos_tol, ori_tol, d_v, d_iters, d_err, d_status,
+                                     static_cast<hipStream_t>(stream), 0, nullptr));
+    return MK_OK;
+  }
   if (p->staged && mk_opt(MK_OPT_STAGED_LOOP) != 0) {
     // Staged problems: one pass of the loop = the structured kernel in its loop mode (error, exit
     // test and bookkeeping of the pass, then the solve of the problems still in the loop), the
@@ -1369,6 +1407,13 @@ int mk_move_to_batch(const mk_problem* p, double* d_q, const double* d_goals, co
   if (!d_q || !d_goals || !d_status) return fail(MK_ERR_INVALID, "null argument");
   if (!p->fused) return fail(MK_ERR_UNSUPPORTED, "waypoint reaching needs a problem the fused path serves");
   if (p->info.target_stride != 7) return fail(MK_ERR_UNSUPPORTED, "waypoint reaching drives exactly one frame task");
+  if (want_f32()) {
+    if (int rc = f32_refusal(p); rc != MK_OK) return rc;
+    MK_HIP(mk_fused32_launch_move_to(p->nc_kernel, p->d_fused, p->info.nq, d_q, d_goals, dt, damping, B, max_steps,
+                                     max_iters, pos_tol, ori_tol, wp->pos_threshold, wp->pos_step_size, wp->rot_threshold,
+                                     d_steps, d_reached, d_solves, d_status, static_cast<hipStream_t>(stream), 0, nullptr));
+    return MK_OK;
+  }
   if (use_coop(p, B)) {
     MK_HIP(mk_coop_launch_move_to(p->nc_kernel, p->d_fused, d_q, d_goals, dt, damping, B, max_steps, max_iters, pos_tol,
                                   ori_tol, wp->pos_threshold, wp->pos_step_size, wp->rot_threshold, d_steps, d_reached,

@@ -2,7 +2,7 @@
 // vector / quaternion / SE3 helpers and the problem descriptors that the host
 // flattens out of mk_model_desc / mk_task_desc / mk_limit_desc.
 //
-// Everything is float64, one IK problem per lane; descriptors are wave-uniform, so
+// Everything is float64 (float32 in the MK_F32 build of the fused kernels), one IK problem per lane; descriptors are wave-uniform, so
 // descriptor reads become scalar loads.
 #pragma once
 
@@ -147,14 +147,106 @@ struct MkFusedExt {
   MkCollPair cpair[MK_MAX_CPAIR];
 };
 
+// ------------------------------------------------------------- scalar type ----
+// The arithmetic type of the kernels.  The library's kernels compute in float64; a translation
+// unit compiled with MK_F32 gets the same source in float32 (mk_fused32.hip): `real` is then a
+// thin wrapper of float whose only purpose is that the float64 literals and descriptor fields of
+// the shared source convert to it instead of promoting the arithmetic to float64.  Arrays in
+// global memory (q, targets, v) stay float64 in both builds.
+#if defined(MK_F32)
+struct real {
+  float v;
+  real() = default;
+  MK_DEV constexpr real(double d) : v((float)d) {}
+  MK_DEV constexpr real(float f) : v(f) {}
+  MK_DEV constexpr real(int i) : v((float)i) {}
+  MK_DEV explicit constexpr operator double() const { return (double)v; }
+  MK_DEV explicit constexpr operator int() const { return (int)v; }
+};
+MK_DEV constexpr real operator+(real a, real b) { return real(a.v + b.v); }
+MK_DEV constexpr real operator-(real a, real b) { return real(a.v - b.v); }
+MK_DEV constexpr real operator*(real a, real b) { return real(a.v * b.v); }
+MK_DEV constexpr real operator/(real a, real b) { return real(a.v / b.v); }
+MK_DEV constexpr real operator-(real a) { return real(-a.v); }
+MK_DEV constexpr real operator+(real a) { return a; }
+MK_DEV real& operator+=(real& a, real b) { a.v += b.v; return a; }
+MK_DEV real& operator-=(real& a, real b) { a.v -= b.v; return a; }
+MK_DEV real& operator*=(real& a, real b) { a.v *= b.v; return a; }
+MK_DEV constexpr bool operator<(real a, real b) { return a.v < b.v; }
+MK_DEV constexpr bool operator>(real a, real b) { return a.v > b.v; }
+MK_DEV constexpr bool operator<=(real a, real b) { return a.v <= b.v; }
+MK_DEV constexpr bool operator>=(real a, real b) { return a.v >= b.v; }
+MK_DEV constexpr bool operator==(real a, real b) { return a.v == b.v; }
+MK_DEV constexpr bool operator!=(real a, real b) { return a.v != b.v; }
+MK_DEV real fabs(real a) { return real(__builtin_fabsf(a.v)); }
+MK_DEV real fmax(real a, real b) { return real(__builtin_fmaxf(a.v, b.v)); }
+MK_DEV real fmin(real a, real b) { return real(__builtin_fminf(a.v, b.v)); }
+MK_DEV real fma(real a, real b, real c) { return real(__builtin_fmaf(a.v, b.v, c.v)); }
+MK_DEV real sqrt(real a) { return real(__builtin_sqrtf(a.v)); }
+MK_DEV real rint(real a) { return real(__builtin_rintf(a.v)); }
+MK_DEV real atan2(real a, real b) { return real(atan2f(a.v, b.v)); }
+MK_DEV real asin(real a) { return real(asinf(a.v)); }
+#define MK_RAW(a) ((a).v)
+constexpr bool MK_IS_F32 = true;
+constexpr float MK_TINY = 1e-30f;   // floor under arguments of rsqrt / rcp that may vanish
+#else
+typedef double real;
+#define MK_RAW(a) (a)
+constexpr bool MK_IS_F32 = false;
+constexpr double MK_TINY = 1e-300;
+#endif
+
 // ------------------------------------------------------------------ math ----
 // Reciprocal / reciprocal square root for normal-range positive-scale arguments:
 // hardware seed (v_rcp_f64 / v_rsq_f64) plus two Newton steps, ~1 ulp, without the
 // scaling and fix-up sequence of a full IEEE division (the operands here are norms,
 // Cholesky pivots, dt and Hessian diagonals, never denormal or infinite).
-MK_DEV double mk_rcp(double x) {
+#if defined(MK_F32)
+// float32: the hardware reciprocal and reciprocal square root are good to 1 ulp as they are.
+MK_DEV real mk_rcp(real x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  double r = __builtin_amdgcn_rcp(x);
+  return real(__builtin_amdgcn_rcpf(x.v));
+#else
+  return real(1.0f / x.v);
+#endif
+}
+MK_DEV real mk_rsqrt(real x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return real(__builtin_amdgcn_rsqf(x.v));
+#else
+  return real(1.0f / __builtin_sqrtf(x.v));
+#endif
+}
+// sin and cos for |x| < 2^15: two-constant reduction by pi/2, degree-9 / degree-8 kernels on
+// [-pi/4, pi/4] (the float32 minimax coefficients of the usual sinf / cosf kernels); about 1 ulp
+// for the joint angles and rotation-vector norms that reach it, NaN beyond the range.
+MK_DEV void mk_sincos(real xr, real* sn, real* cs) {
+  const float x = xr.v;
+  const float k = __builtin_rintf(x * 0.636619772367581343f);
+  float r = __builtin_fmaf(-k, 1.57079637050628662109375f, x);
+  r = __builtin_fmaf(-k, -4.37113900018624283e-8f, r);
+  const float z = r * r;
+  float ps = __builtin_fmaf(z, 2.7183114939898219064e-6f, -1.98393348360966317347e-4f);
+  ps = __builtin_fmaf(z, ps, 8.3333293858894631756e-3f);
+  ps = __builtin_fmaf(z, ps, -1.66666666416265235595e-1f);
+  const float sr = __builtin_fmaf(r * z, ps, r);
+  float pc = __builtin_fmaf(z, 2.43904487962774090654e-5f, -1.38867637746099294692e-3f);
+  pc = __builtin_fmaf(z, pc, 4.16666233237390631894e-2f);
+  pc = __builtin_fmaf(z, pc, -4.99999997251031003120e-1f);
+  const float cr = __builtin_fmaf(z, pc, 1.0f);
+  const bool ok = __builtin_fabsf(x) < 32768.0f;
+  const int q = ok ? (int)k : 0;
+  float s = (q & 1) ? cr : sr;
+  float c = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s : s;
+  c = ((q + 1) & 2) ? -c : c;
+  *sn = real(ok ? s : NAN);
+  *cs = real(ok ? c : NAN);
+}
+#else
+MK_DEV real mk_rcp(real x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  real r = __builtin_amdgcn_rcp(x);
   r = fma(fma(-x, r, 1.0), r, r);
   r = fma(fma(-x, r, 1.0), r, r);
   return r;
@@ -162,10 +254,10 @@ MK_DEV double mk_rcp(double x) {
   return 1.0 / x;
 #endif
 }
-MK_DEV double mk_rsqrt(double x) {
+MK_DEV real mk_rsqrt(real x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  double y = __builtin_amdgcn_rsq(x);
-  const double hx = 0.5 * x;
+  real y = __builtin_amdgcn_rsq(x);
+  const real hx = 0.5 * x;
   y = fma(fma(-hx * y, y, 0.5), y, y);
   y = fma(fma(-hx * y, y, 0.5), y, y);
   return y;
@@ -177,32 +269,33 @@ MK_DEV double mk_rsqrt(double x) {
 // two-constant Cody-Waite reduction by pi/2 with fused multiply-adds, then the classic
 // degree-13 / degree-14 minimax kernels on [-pi/4, pi/4]; < 1 ulp.  Larger or non-finite
 // arguments give NaN, which the kernels report as non-finite input.
-MK_DEV void mk_sincos(double x, double* sn, double* cs) {
-  const double k = rint(x * 0.63661977236758134308);
-  double r = fma(-k, 1.57079632679489655800e+00, x);
+MK_DEV void mk_sincos(real x, real* sn, real* cs) {
+  const real k = rint(x * 0.63661977236758134308);
+  real r = fma(-k, 1.57079632679489655800e+00, x);
   r = fma(-k, 6.12323399573676603587e-17, r);
-  const double z = r * r;
-  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  const real z = r * r;
+  real ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
   ps = fma(z, ps, 2.75573137070700676789e-06);
   ps = fma(z, ps, -1.98412698298579493134e-04);
   ps = fma(z, ps, 8.33333333332248946124e-03);
   ps = fma(z, ps, -1.66666666666666324348e-01);
-  const double sr = fma(r * z, ps, r);
-  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  const real sr = fma(r * z, ps, r);
+  real pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
   pc = fma(z, pc, -2.75573143513906633035e-07);
   pc = fma(z, pc, 2.48015872894767294178e-05);
   pc = fma(z, pc, -1.38888888888741095749e-03);
   pc = fma(z, pc, 4.16666666666666019037e-02);
-  const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const real cr = fma(z * z, pc, fma(-0.5, z, 1.0));
   const bool ok = fabs(x) < 1073741824.0;
   const int q = ok ? (int)k : 0;
-  double s = (q & 1) ? cr : sr;
-  double c = (q & 1) ? sr : cr;
+  real s = (q & 1) ? cr : sr;
+  real c = (q & 1) ? sr : cr;
   s = (q & 2) ? -s : s;
   c = ((q + 1) & 2) ? -c : c;
   *sn = ok ? s : NAN;
   *cs = ok ? c : NAN;
 }
+#endif
 
 // Keeps the instruction scheduler from moving anything across this point.  The kernels
 // are long straight-line blocks full of scalar loads of per-slot constants; unfenced, the
@@ -219,8 +312,8 @@ MK_DEV void mk_sincos(double x, double* sn, double* cs) {
 // MK_SCHED_FENCE (a fence alone only orders memory operations while the block is first
 // linearised; arithmetic would still drift away from the loads it was meant to overlap).
 #if defined(__HIP_DEVICE_COMPILE__)
-#define MK_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-#define MK_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+#define MK_PIN4(a, b, c, d) asm volatile("" : "+v"(MK_RAW(a)), "+v"(MK_RAW(b)), "+v"(MK_RAW(c)), "+v"(MK_RAW(d)))
+#define MK_PIN3(a, b, c) asm volatile("" : "+v"(MK_RAW(a)), "+v"(MK_RAW(b)), "+v"(MK_RAW(c)))
 #else
 #define MK_PIN4(a, b, c, d) ((void)0)
 #define MK_PIN3(a, b, c) ((void)0)
@@ -247,16 +340,16 @@ MK_DEV bool mk_wave_none(bool pending) {
 #endif
 }
 
-struct V3 { double x, y, z; };
-struct Q4 { double w, x, y, z; };
-struct M3 { double m[9]; };  // row-major
+struct V3 { real x, y, z; };
+struct Q4 { real w, x, y, z; };
+struct M3 { real m[9]; };  // row-major
 
-MK_DEV V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+MK_DEV V3 v3(real x, real y, real z) { return V3{x, y, z}; }
 MK_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 MK_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
-MK_DEV V3 operator*(double s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+MK_DEV V3 operator*(real s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
 MK_DEV V3 neg(V3 a) { return V3{-a.x, -a.y, -a.z}; }
-MK_DEV double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+MK_DEV real dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 MK_DEV V3 cross(V3 a, V3 b) {
   return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
@@ -279,17 +372,17 @@ MK_DEV V3 qrot(Q4 q, V3 v) {
 
 // mju_normalize4: a vanishing quaternion maps to identity.
 MK_DEV Q4 qnormalize(Q4 q) {
-  const double n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+  const real n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
   if (n2 < MK_MINVAL * MK_MINVAL) return Q4{1.0, 0.0, 0.0, 0.0};
-  const double r = mk_rsqrt(n2);
+  const real r = mk_rsqrt(n2);
   return Q4{q.w * r, q.x * r, q.y * r, q.z * r};
 }
 
 // mju_quat2Mat.
 MK_DEV M3 q2m(Q4 q) {
-  double q00 = q.w * q.w, q11 = q.x * q.x, q22 = q.y * q.y, q33 = q.z * q.z;
-  double q01 = q.w * q.x, q02 = q.w * q.y, q03 = q.w * q.z;
-  double q12 = q.x * q.y, q13 = q.x * q.z, q23 = q.y * q.z;
+  real q00 = q.w * q.w, q11 = q.x * q.x, q22 = q.y * q.y, q33 = q.z * q.z;
+  real q01 = q.w * q.x, q02 = q.w * q.y, q03 = q.w * q.z;
+  real q12 = q.x * q.y, q13 = q.x * q.z, q23 = q.y * q.z;
   M3 r;
   r.m[0] = q00 + q11 - q22 - q33; r.m[1] = 2 * (q12 - q03); r.m[2] = 2 * (q13 + q02);
   r.m[3] = 2 * (q12 + q03); r.m[4] = q00 - q11 + q22 - q33; r.m[5] = 2 * (q23 - q01);
@@ -316,9 +409,9 @@ MK_DEV M3 mmul(const M3& a, const M3& b) {
   return r;
 }
 // I + a*[w]x + b*[w]x^2
-MK_DEV M3 rodrigues_like(V3 w, double a, double b) {
-  double xx = w.x * w.x, yy = w.y * w.y, zz = w.z * w.z;
-  double xy = w.x * w.y, xz = w.x * w.z, yz = w.y * w.z;
+MK_DEV M3 rodrigues_like(V3 w, real a, real b) {
+  real xx = w.x * w.x, yy = w.y * w.y, zz = w.z * w.z;
+  real xy = w.x * w.y, xz = w.x * w.z, yz = w.y * w.z;
   M3 r;
   r.m[0] = 1.0 - b * (yy + zz); r.m[1] = -a * w.z + b * xy; r.m[2] = a * w.y + b * xz;
   r.m[3] = a * w.z + b * xy; r.m[4] = 1.0 - b * (xx + zz); r.m[5] = -a * w.x + b * yz;
@@ -344,27 +437,27 @@ MK_DEV M3 mtrans(const M3& a) {
 // cases of the reference (small angle, |w| ~ 0, general) are all evaluated and selected,
 // so that the code stays straight-line.
 MK_DEV V3 so3_log(Q4 q) {
-  const double n2 = q.x * q.x + q.y * q.y + q.z * q.z;
-  const double iw = mk_rcp(q.w);
-  const double f_small = 2.0 * iw - 2.0 / 3.0 * n2 * (iw * iw * iw);
-  const double n2s = fmax(n2, 1e-300);
-  const double rn = mk_rsqrt(n2s), n = n2s * rn;
-  const double f_pi = (q.w > 0.0 ? MK_PI : -MK_PI) * rn;
-  const double f_gen = 2.0 * atan2(q.w < 0 ? -n : n, fabs(q.w)) * rn;
-  const double f = (n2 < MK_LIE_EPS) ? f_small : ((fabs(q.w) < MK_LIE_EPS) ? f_pi : f_gen);
+  const real n2 = q.x * q.x + q.y * q.y + q.z * q.z;
+  const real iw = mk_rcp(q.w);
+  const real f_small = 2.0 * iw - 2.0 / 3.0 * n2 * (iw * iw * iw);
+  const real n2s = fmax(n2, MK_TINY);
+  const real rn = mk_rsqrt(n2s), n = n2s * rn;
+  const real f_pi = (q.w > 0.0 ? MK_PI : -MK_PI) * rn;
+  const real f_gen = 2.0 * atan2(q.w < 0 ? -n : n, fabs(q.w)) * rn;
+  const real f = (n2 < MK_LIE_EPS) ? f_small : ((fabs(q.w) < MK_LIE_EPS) ? f_pi : f_gen);
   return V3{f * q.x, f * q.y, f * q.z};
 }
 
 // SO3.exp of a rotation vector (mink/lie/so3.py:158-173): unit quaternion, with the
 // reference's series below its small-angle switch.
 MK_DEV Q4 so3_exp(V3 w) {
-  const double t2 = dot(w, w);
+  const real t2 = dot(w, w);
   const bool small = t2 < MK_LIE_EPS;
-  const double th = sqrt(small ? 1.0 : t2);
-  double sn, cs;
+  const real th = sqrt(small ? 1.0 : t2);
+  real sn, cs;
   mk_sincos(0.5 * th, &sn, &cs);
-  const double re = small ? 1.0 - t2 / 8.0 + t2 * t2 / 384.0 : cs;
-  const double im = small ? 0.5 - t2 / 48.0 + t2 * t2 / 3840.0 : sn / th;
+  const real re = small ? 1.0 - t2 / 8.0 + t2 * t2 / 384.0 : cs;
+  const real im = small ? 0.5 - t2 / 48.0 + t2 * t2 / 3840.0 : sn / th;
   return Q4{re, im * w.x, im * w.y, im * w.z};
 }
 
@@ -378,16 +471,27 @@ MK_DEV V3 quat_rpy(Q4 q) {
 
 struct Twist { V3 v, w; };
 
+// (1 - (theta/2) cot(theta/2)) / theta^2 as its series in t2 = theta^2 (t2 < 1; next term
+// 1e-10 t2^5).  The float32 build uses it where the closed forms of SE3.log and SO3.ljacinv --
+// which are this same function -- lose their leading digits to cancellation.
+MK_DEV real mk_half_cot_series(real t2) {
+  real p = fma(t2, 1.0 / 47900160.0, 1.0 / 1209600.0);
+  p = fma(t2, p, 1.0 / 30240.0);
+  p = fma(t2, p, 1.0 / 720.0);
+  return fma(t2, p, 1.0 / 12.0);
+}
+
 // SE3.log (mink/lie/se3.py:159-185) of the transform (q, t).
 MK_DEV Twist se3_log(Q4 q, V3 t) {
   const V3 w = so3_log(q);
-  const double t2 = dot(w, w);
-  const double t2s = fmax(t2, 1e-300);
-  const double rth = mk_rsqrt(t2s), th = t2s * rth;
-  double s, c;
+  const real t2 = dot(w, w);
+  const real t2s = fmax(t2, MK_TINY);
+  const real rth = mk_rsqrt(t2s), th = t2s * rth;
+  real s, c;
   mk_sincos(0.5 * th, &s, &c);
-  const double coef_gen = (1.0 - th * c * mk_rcp(2.0 * s)) * (rth * rth);
-  const double coef = (t2 < MK_LIE_EPS) ? 1.0 / 12.0 : coef_gen;
+  const real coef_gen = (1.0 - th * c * mk_rcp(2.0 * s)) * (rth * rth);
+  real coef = (t2 < MK_LIE_EPS) ? 1.0 / 12.0 : coef_gen;
+  if (MK_IS_F32 && t2 < 1.0) coef = mk_half_cot_series(t2);   // the closed form cancels in float32
   M3 Vinv = rodrigues_like(w, -0.5, coef);
   return Twist{mul(Vinv, t), w};
 }
@@ -401,25 +505,32 @@ MK_DEV Twist se3_log(Q4 q, V3 t) {
 //   WV + VW = v w' + w v' - 2 s I,   WVW = -s W,   VWW - (VWW)' = [n x w]x - 2 s W,
 //   WVWW + WWVW = -2 s (w w' - |w|^2 I),
 // i.e. a skew part [v/2 - (b + c) s w - c (n x w)]x plus a symmetric part.
-MK_DEV M3 se3_Q_closed(Twist xi, double t2, double rth, double th, double s, double c) {
-  const double it2 = rth * rth;
-  const double ith = rth;
-  const double Bc = (th - s) * it2 * ith;
-  const double Cc = (1.0 - 0.5 * t2 - c) * it2 * it2;
-  const double Dc = (2.0 * th - 3.0 * s + th * c) * (0.5 * it2 * it2 * ith);
+MK_DEV M3 se3_Q_closed(Twist xi, real t2, real rth, real th, real s, real c) {
+  const real it2 = rth * rth;
+  const real ith = rth;
+  real Bc = (th - s) * it2 * ith;
+  real Cc = (1.0 - 0.5 * t2 - c) * it2 * it2;
+  real Dc = (2.0 * th - 3.0 * s + th * c) * (0.5 * it2 * it2 * ith);
+  if (MK_IS_F32 && t2 < 1.0) {
+    // float32: the numerators above are differences of O(1) terms that leave theta^3 .. theta^5;
+    // their series in t2 instead (next terms below 1e-8)
+    Bc = fma(t2, fma(t2, fma(t2, -1.0 / 362880.0, 1.0 / 5040.0), -1.0 / 120.0), 1.0 / 6.0);
+    Cc = fma(t2, fma(t2, fma(t2, 1.0 / 3628800.0, -1.0 / 40320.0), 1.0 / 720.0), -1.0 / 24.0);
+    Dc = 0.5 * fma(t2, fma(t2, fma(t2, -1.0 / 4989600.0, 1.0 / 60480.0), -1.0 / 1260.0), 1.0 / 60.0);
+  }
   const V3 v = xi.v, w = xi.w;
-  const double sv = dot(v, w);
+  const real sv = dot(v, w);
   const V3 n = cross(v, w);
   const V3 k = 0.5 * v - ((Bc + Cc) * sv) * w - Cc * cross(n, w);   // skew part [k]x
-  const double d2 = -2.0 * sv * Dc;
-  const double di = -2.0 * sv * Bc - d2 * t2;                         // multiple of I
+  const real d2 = -2.0 * sv * Dc;
+  const real di = -2.0 * sv * Bc - d2 * t2;                         // multiple of I
   M3 Q;
   Q.m[0] = di + 2.0 * Bc * v.x * w.x + d2 * w.x * w.x;
   Q.m[4] = di + 2.0 * Bc * v.y * w.y + d2 * w.y * w.y;
   Q.m[8] = di + 2.0 * Bc * v.z * w.z + d2 * w.z * w.z;
-  const double sxy = Bc * (v.x * w.y + v.y * w.x) + d2 * w.x * w.y;
-  const double sxz = Bc * (v.x * w.z + v.z * w.x) + d2 * w.x * w.z;
-  const double syz = Bc * (v.y * w.z + v.z * w.y) + d2 * w.y * w.z;
+  const real sxy = Bc * (v.x * w.y + v.y * w.x) + d2 * w.x * w.y;
+  const real sxz = Bc * (v.x * w.z + v.z * w.x) + d2 * w.x * w.z;
+  const real syz = Bc * (v.y * w.z + v.z * w.y) + d2 * w.y * w.z;
   Q.m[1] = sxy - k.z; Q.m[3] = sxy + k.z;
   Q.m[2] = sxz + k.y; Q.m[6] = sxz - k.y;
   Q.m[5] = syz - k.x; Q.m[7] = syz + k.x;
@@ -430,18 +541,22 @@ MK_DEV M3 se3_Q_closed(Twist xi, double t2, double rth, double th, double s, dou
 // (mink/lie/se3.py:210-249, mink/lie/so3.py:214-226); Ji = I, B = 0 when the reference
 // returns exactly I6 (theta^2 below the switch).
 MK_DEV void se3_ljacinv_blocks(Twist xi, M3& Ji, M3& B) {
-  const double t2 = dot(xi.w, xi.w);
-  if (t2 < MK_LIE_EPS) {
+  const real t2 = dot(xi.w, xi.w);
+  // (float32: no switch to the identity -- the series below are good down to theta = 0, and the
+  // reference's float32 switch, theta^2 < 1e-5, would cost three digits of the Jacobian)
+  if (!MK_IS_F32 && t2 < MK_LIE_EPS) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) { Ji.m[i] = (i % 4 == 0) ? 1.0 : 0.0; B.m[i] = 0.0; }
     return;
   }
-  const double rth = mk_rsqrt(t2), th = t2 * rth;
-  double s, c;
+  const real t2s = MK_IS_F32 ? fmax(t2, MK_TINY) : t2;
+  const real rth = mk_rsqrt(t2s), th = t2s * rth;
+  real s, c;
   mk_sincos(th, &s, &c);
   // SO3.ljacinv switches on theta (not theta^2); theta >= 1e-5 here, so closed form.
-  const double it2 = rth * rth;
-  const double A = it2 * (1.0 - (th * s * mk_rcp(2.0 * (1.0 - c))));
+  const real it2 = rth * rth;
+  real A = it2 * (1.0 - (th * s * mk_rcp(2.0 * (1.0 - c))));
+  if (MK_IS_F32 && t2 < 1.0) A = mk_half_cot_series(t2);
   Ji = rodrigues_like(xi.w, -0.5, A);
   const M3 Q = se3_Q_closed(xi, t2, rth, th, s, c);
   M3 JQ = mmul(Ji, Q);
@@ -459,13 +574,13 @@ MK_DEV Twist frame_error(Q4 Q, V3 t, const M3& R, Q4 Qt, V3 pt) { return se3_log
 // straight line to the goal position (the goal itself once within pos_thr), half-way along
 // the geodesic to the goal orientation -- and whether the goal counts as reached (position
 // within pos_thr and the norm of the x-y-z Euler angles of goal * current^-1 below rot_thr).
-MK_DEV bool waypoint_step(Q4 Qc, V3 tc, Q4 Qg, V3 pg, double pos_thr, double pos_step, double rot_thr, Q4& Qt,
+MK_DEV bool waypoint_step(Q4 Qc, V3 tc, Q4 Qg, V3 pg, real pos_thr, real pos_step, real rot_thr, Q4& Qt,
                           V3& pt) {
   const V3 delta = pg - tc;
-  const double dist = sqrt(dot(delta, delta));
+  const real dist = sqrt(dot(delta, delta));
   const bool pos_reached = dist < pos_thr;
-  const double step = fmin(dist, pos_step);
-  const V3 moved = tc + (step / fmax(dist, 1e-300)) * delta;
+  const real step = fmin(dist, pos_step);
+  const V3 moved = tc + (step / fmax(dist, MK_TINY)) * delta;
   pt = pos_reached ? pg : moved;
   const V3 half = 0.5 * so3_log(qmul(qconj(Qc), Qg));
   Qt = qmul(Qc, so3_exp(half));

@@ -16,9 +16,19 @@
 // the dense block is solved by a dual active-set method (Goldfarb-Idnani iterates)
 // with the active bounds expressed as lane masks, so 64 problems with different
 // active sets run one instruction stream.
+// This file is compiled twice: as it is (float64, every kernel), and with MK_F32 from
+// mk_fused32.hip: the step, loop and rollout kernels of problems without collision rows in
+// float32 arithmetic, under launcher names of their own.
+#if defined(MK_F32)
+#define mk_fused_launch_step mk_fused32_launch_step
+#define mk_fused_launch_iterate mk_fused32_launch_iterate
+#define mk_fused_launch_move_to mk_fused32_launch_move_to
+#endif
 #include "mk_device.h"
 #include "mk_generic.h"
+#if !defined(MK_F32)
 #include "mk_geom.h"
+#endif
 #include "mk_options.h"
 
 #include <algorithm>
@@ -45,52 +55,58 @@ MK_DEV constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j
 // GPU the Hessian of each lane lives in LDS as element e of lane l at p[e * 64 + l]
 // (conflict-free b64 reads, compile-time offsets); the host test build uses stride 1.
 struct HView {
-  const double* p;
+  const real* p;
   int stride;
-  MK_DEV double operator()(int e) const { return p[e * stride]; }
+  MK_DEV real operator()(int e) const { return p[e * stride]; }
 };
 
 // Cholesky factor of H with the rows/columns in `act` replaced by identity.
 // L holds the strict lower triangle, Ld the reciprocals of the diagonal.
+// Returns false in float64.  In float32: whether a pivot came out below 1e-6 of its diagonal
+// entry, i.e. was lost to rounding (a Hessian whose condition number float32 cannot carry).
 template <int N>
-MK_DEV void chol_masked(HView H, uint32_t act, double (&L)[N * (N + 1) / 2], double (&Ld)[N]) {
+MK_DEV bool chol_masked(HView H, uint32_t act, real (&L)[N * (N + 1) / 2], real (&Ld)[N]) {
   MK_STAT(3);
-  double mk[N];
+  bool lost = false;
+  real mk[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) mk[i] = ((act >> i) & 1u) ? 0.0 : 1.0;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    double s = mk[j] * H(tri(j, j)) + (1.0 - mk[j]);
+    real s = mk[j] * H(tri(j, j)) + (1.0 - mk[j]);
+    const real hjj = s;
 #pragma unroll
     for (int k = 0; k < j; ++k) s -= L[tri(j, k)] * L[tri(j, k)];
-    s = fmax(s, 1e-300);
-    const double r = mk_rsqrt(s);
+    if (MK_IS_F32) lost |= !(s > 1e-6 * hjj);
+    s = fmax(s, MK_TINY);
+    const real r = mk_rsqrt(s);
     Ld[j] = r;
-    const double rm = r * mk[j];   // a masked column is zero below its unit diagonal
+    const real rm = r * mk[j];   // a masked column is zero below its unit diagonal
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {
       // rows of masked variables are zero: L[i][k] = 0 for k < j, so only the H term needs mk[i]
-      double t = H(tri(i, j)) * mk[i];
+      real t = H(tri(i, j)) * mk[i];
 #pragma unroll
       for (int k = 0; k < j; ++k) t -= L[tri(i, k)] * L[tri(j, k)];
       L[tri(i, j)] = t * rm;
     }
   }
+  return lost;
 }
 
 // In-place solve of (L L') y = b.
 template <int N>
-MK_DEV void chol_solve(const double (&L)[N * (N + 1) / 2], const double (&Ld)[N], double (&b)[N]) {
+MK_DEV void chol_solve(const real (&L)[N * (N + 1) / 2], const real (&Ld)[N], real (&b)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    double s = b[i];
+    real s = b[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) s -= L[tri(i, k)] * b[k];
     b[i] = s * Ld[i];
   }
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {
-    double s = b[i];
+    real s = b[i];
 #pragma unroll
     for (int k = i + 1; k < N; ++k) s -= L[tri(k, i)] * b[k];
     b[i] = s * Ld[i];
@@ -99,14 +115,14 @@ MK_DEV void chol_solve(const double (&L)[N * (N + 1) / 2], const double (&Ld)[N]
 
 // y = H x for the packed symmetric H, reading every stored entry once.
 template <int N>
-MK_DEV void symv(HView H, const double (&x)[N], double (&y)[N]) {
+MK_DEV void symv(HView H, const real (&x)[N], real (&y)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) y[i] = H(tri(i, i)) * x[i];
 #pragma unroll
   for (int i = 1; i < N; ++i) {
 #pragma unroll
     for (int j = 0; j < i; ++j) {
-      const double h = H(tri(i, j));
+      const real h = H(tri(i, j));
       y[i] += h * x[j];
       y[j] += h * x[i];
     }
@@ -132,25 +148,27 @@ MK_DEV void symv(HView H, const double (&x)[N], double (&y)[N]) {
 // Every change of A refactors H with the rows/columns of A replaced by identity,
 // which keeps 64 different active sets on one instruction stream.
 // act/upper: in = guess (used when warm), out = final active set and its sides.
-// Returns 0 ok / 1 iteration limit / 2 infeasible.
+// Returns 0 ok / 1 iteration limit / 2 infeasible / 3 (float32 only) a factorisation lost a pivot
+// to rounding: the answer is not to be trusted.
 template <int N>
-MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const double (&hi)[N], double (&x)[N],
+MK_DEV int box_qp(HView H, const real (&c)[N], const real (&lo)[N], const real (&hi)[N], real (&x)[N],
                   uint32_t& act_io, uint32_t& upper_io, bool warm) {
-  constexpr double kTol = 1e-14;
+  // bound violations below kTol count as satisfied (x is a step dq of a few 1e-2 at most)
+  const real kTol = MK_IS_F32 ? 1e-7 : 1e-14;
   // a cold start has many bounds to find and profits from more guessing rounds; a warm
   // start that does not settle quickly is usually cycling and is better off in phase 2
   const int kGuessRounds = warm ? 3 : 6;
   MK_STAT(0);
-  double L[N * (N + 1) / 2], Ld[N];
+  real L[N * (N + 1) / 2], Ld[N];
   uint32_t act = 0u, upper = upper_io;
-  bool bad = false;
+  bool bad = false, lost = false;
 #pragma unroll
   for (int i = 0; i < N; ++i) bad |= !(lo[i] <= hi[i]);
   if (warm) {
     act = act_io;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const double b = ((upper >> i) & 1u) ? hi[i] : lo[i];
+      const real b = ((upper >> i) & 1u) ? hi[i] : lo[i];
       if (!(fabs(b) < INFINITY)) act &= ~(1u << i);
     }
   }
@@ -159,7 +177,7 @@ MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const do
     // violates (about half the rounds of starting from the empty set)
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const double xi = -c[i] * mk_rcp(H(tri(i, i)));
+      const real xi = -c[i] * mk_rcp(H(tri(i, i)));
       if (xi > hi[i]) { act |= (1u << i); upper |= (1u << i); }
       if (xi < lo[i]) { act |= (1u << i); upper &= ~(1u << i); }
     }
@@ -178,8 +196,8 @@ MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const do
       // H is re-read from LDS every round on purpose: hoisting the loads would pin the
       // whole matrix in registers next to the factor
       asm volatile("" ::: "memory");
-      chol_masked<N>(H, act, L, Ld);
-      double xa[N], hx[N];
+      lost |= chol_masked<N>(H, act, L, Ld);
+      real xa[N], hx[N];
 #pragma unroll
       for (int i = 0; i < N; ++i)
         xa[i] = ((act >> i) & 1u) ? (((upper >> i) & 1u) ? hi[i] : lo[i]) : 0.0;
@@ -191,9 +209,9 @@ MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const do
       uint32_t drop = 0u, add = 0u, add_up = 0u;
 #pragma unroll
       for (int i = 0; i < N; ++i) {
-        const double g = c[i] + hx[i];
+        const real g = c[i] + hx[i];
         const bool a = (act >> i) & 1u;
-        const double ui = ((upper >> i) & 1u) ? -g : g;
+        const real ui = ((upper >> i) & 1u) ? -g : g;
         if (a && ui < 0.0) drop |= (1u << i);
         if (!a && x[i] - hi[i] > kTol) { add |= (1u << i); add_up |= (1u << i); }
         if (!a && lo[i] - x[i] > kTol) add |= (1u << i);
@@ -212,18 +230,18 @@ MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const do
   int status = bad ? 2 : 0;
   bool done = bad;
   int p = -1;
-  double sgn = 0.0, bound = 0.0, up_new = 0.0;
+  real sgn = 0.0, bound = 0.0, up_new = 0.0;
   // multipliers of the active bounds: phase 1 only needs their signs, so they are formed
   // here, once, and only if some lane of the wave enters phase 2 at all
-  double u[N];
+  real u[N];
   bool have_u = false;
   for (int it = 0; it < 6 * N + 8; ++it) {
     if (!done && p < 0) {
-      double worst = kTol;
+      real worst = kTol;
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         const bool free_i = !((act >> i) & 1u);
-        const double vh = x[i] - hi[i], vl = lo[i] - x[i];
+        const real vh = x[i] - hi[i], vl = lo[i] - x[i];
         if (free_i && vh > worst) { worst = vh; p = i; sgn = 1.0; bound = hi[i]; }
         if (free_i && vl > worst) { worst = vl; p = i; sgn = -1.0; bound = lo[i]; }
       }
@@ -234,40 +252,40 @@ MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const do
     if (!have_u) {   // wave-uniform
       have_u = true;
       asm volatile("" ::: "memory");
-      double hx[N];
+      real hx[N];
       symv<N>(H, x, hx);
 #pragma unroll
       for (int i = 0; i < N; ++i) {
-        const double g = c[i] + hx[i];
-        const double ui = ((upper >> i) & 1u) ? -g : g;
+        const real g = c[i] + hx[i];
+        const real ui = ((upper >> i) & 1u) ? -g : g;
         u[i] = (((act >> i) & 1u) && ui > 0.0) ? ui : 0.0;
       }
     }
     if (!done) {
       MK_STAT(2);
       asm volatile("" ::: "memory");
-      double z[N], r[N];
+      real z[N], r[N];
 #pragma unroll
       for (int i = 0; i < N; ++i) z[i] = (i == p) ? -sgn : 0.0;
       chol_solve<N>(L, Ld, z);
       symv<N>(H, z, r);
       // dual step direction of the active bounds and the blocking one
-      double t1 = INFINITY;
+      real t1 = INFINITY;
       int kb = -1;
-      double xp = 0.0, zp = 0.0;
+      real xp = 0.0, zp = 0.0;
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         const bool a = (act >> k) & 1u;
         r[k] = ((upper >> k) & 1u) ? r[k] : -r[k];
         if (a && r[k] > 0.0) {
-          double t = u[k] * mk_rcp(r[k]);
+          real t = u[k] * mk_rcp(r[k]);
           if (t < t1) { t1 = t; kb = k; }
         }
         if (k == p) { xp = x[k]; zp = z[k]; }
       }
-      const double t2 = (bound - xp) * mk_rcp(zp);
+      const real t2 = (bound - xp) * mk_rcp(zp);
       const bool full = t2 <= t1;
-      const double t = full ? t2 : t1;
+      const real t = full ? t2 : t1;
       up_new += t;
 #pragma unroll
       for (int k = 0; k < N; ++k) {
@@ -284,10 +302,16 @@ MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const do
       } else {
         act &= ~(1u << kb);
       }
-      chol_masked<N>(H, act, L, Ld);
+      lost |= chol_masked<N>(H, act, L, Ld);
     }
   }
   if (!done) status = 1;
+  if (MK_IS_F32) {
+    // float32: rounding may leave x a few ulps outside a bound it sits on
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = fmin(fmax(x[i], lo[i]), hi[i]);
+    if (lost && status == 0) status = 3;
+  }
   act_io = act;
   upper_io = upper;
   return status;
@@ -298,7 +322,7 @@ MK_DEV int box_qp(HView H, const double (&c)[N], const double (&lo)[N], const do
 // the pose of the task frame and the frame-task error e = log(T_wb^-1 T_wt).
 template <int NC>
 struct ChainJac {
-  double J[6][NC];
+  real J[6][NC];
   Twist e;
 };
 
@@ -313,7 +337,7 @@ struct ChainJac {
 // intermediates.  Hinges, slides and padding slots share one instruction stream (the
 // `hinge` factor of the slot selects), so the pass is straight-line code.
 template <int NC, bool CAP = false>
-MK_DEV void chain_jac_pose(const MkFusedDesc* __restrict__ D, const double (&qc)[NC], ChainJac<NC>& cj, Q4& Q, V3& t,
+MK_DEV void chain_jac_pose(const MkFusedDesc* __restrict__ D, const real (&qc)[NC], ChainJac<NC>& cj, Q4& Q, V3& t,
                            M3& R, int cap_slot = 0, Q4* Qcap = nullptr, V3* tcap = nullptr) {
   Q = Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]};
   t = v3(D->post_pos[0], D->post_pos[1], D->post_pos[2]);
@@ -326,11 +350,11 @@ MK_DEV void chain_jac_pose(const MkFusedDesc* __restrict__ D, const double (&qc)
       *tcap = t;
     }
     const MkSegC nx = D->segc[k > 0 ? k - 1 : 0];   // requested one slot ahead
-    const double h = s.hinge;
-    const double th = h * qc[k];       // hinge angle (0 for a slide)
-    double sn, cs;
+    const real h = s.hinge;
+    const real th = h * qc[k];       // hinge angle (0 for a slide)
+    real sn, cs;
     mk_sincos(0.5 * th, &sn, &cs);
-    const double hx = h * t.x, hy = h * t.y, sl = s.slide;
+    const real hx = h * t.x, hy = h * t.y, sl = s.slide;
     cj.J[0][k] = fma(hx, R.m[3], fma(-hy, R.m[0], sl * R.m[6]));
     cj.J[1][k] = fma(hx, R.m[4], fma(-hy, R.m[1], sl * R.m[7]));
     cj.J[2][k] = fma(hx, R.m[5], fma(-hy, R.m[2], sl * R.m[8]));
@@ -362,7 +386,7 @@ MK_DEV void chain_jac_pose(const MkFusedDesc* __restrict__ D, const double (&qc)
 }
 
 template <int NC>
-MK_DEV void chain_jac(const MkFusedDesc* __restrict__ D, const double (&qc)[NC], Q4 Qt, V3 pt, ChainJac<NC>& cj) {
+MK_DEV void chain_jac(const MkFusedDesc* __restrict__ D, const real (&qc)[NC], Q4 Qt, V3 pt, ChainJac<NC>& cj) {
   Q4 Q;
   V3 t;
   M3 R;
@@ -372,14 +396,14 @@ MK_DEV void chain_jac(const MkFusedDesc* __restrict__ D, const double (&qc)[NC],
 
 // World pose (Q, t) of the task frame alone: the recursion of chain_jac without columns.
 template <int NC>
-MK_DEV void chain_pose(const MkFusedDesc* __restrict__ D, const double (&qc)[NC], Q4& Q, V3& t) {
+MK_DEV void chain_pose(const MkFusedDesc* __restrict__ D, const real (&qc)[NC], Q4& Q, V3& t) {
   Q = Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]};
   t = v3(D->post_pos[0], D->post_pos[1], D->post_pos[2]);
   MkSegC s = D->segc[NC - 1];
 #pragma unroll
   for (int k = NC - 1; k >= 0; --k) {
     const MkSegC nx = D->segc[k > 0 ? k - 1 : 0];
-    double sn, cs;
+    real sn, cs;
     mk_sincos(0.5 * (s.hinge * qc[k]), &sn, &cs);
     t.z = fma(s.slide, qc[k], t.z);
     const Q4 Qs = Q4{s.pq[0] * cs - s.pq[3] * sn, s.pq[1] * cs + s.pq[2] * sn, s.pq[2] * cs - s.pq[1] * sn,
@@ -394,7 +418,7 @@ MK_DEV void chain_pose(const MkFusedDesc* __restrict__ D, const double (&qc)[NC]
 }
 
 template <int NC>
-MK_DEV void store_chain_q(const MkFusedDesc* __restrict__ D, double* row, const double (&qc)[NC]) {
+MK_DEV void store_chain_q(const MkFusedDesc* __restrict__ D, real* row, const real (&qc)[NC]) {
 #pragma unroll
   for (int k = 0; k < NC; ++k)
     if (D->seg_dof[k] >= 0) row[D->seg_qadr[k]] = qc[k];
@@ -403,10 +427,10 @@ MK_DEV void store_chain_q(const MkFusedDesc* __restrict__ D, double* row, const 
 // Chain coordinates of one problem from its q row; padding slots read as 0 so that they
 // neither rotate nor translate.
 template <int NC>
-MK_DEV void load_chain_q(const MkFusedDesc* __restrict__ D, const double* row, double (&qc)[NC]) {
+MK_DEV void load_chain_q(const MkFusedDesc* __restrict__ D, const real* row, real (&qc)[NC]) {
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
-    const double v = row[D->seg_qadr[k]];
+    const real v = row[D->seg_qadr[k]];
     qc[k] = (D->seg_dof[k] >= 0) ? v : 0.0;
   }
 }
@@ -414,8 +438,8 @@ MK_DEV void load_chain_q(const MkFusedDesc* __restrict__ D, const double* row, d
 // True when a coordinate outside the chain (scalar dofs, free-joint poses) is not finite.
 // Those coordinates only change by the kernels' own finite updates, so one look per launch
 // is enough.
-MK_DEV bool rest_nonfinite(const MkFusedDesc* __restrict__ D, const double* row) {
-  double acc = 0.0;
+MK_DEV bool rest_nonfinite(const MkFusedDesc* __restrict__ D, const real* row) {
+  real acc = 0.0;
   for (int d = 0; d < D->nd; ++d) acc += 0.0 * row[D->ddof[d].qadr];
   for (int f = 0; f < D->nfree; ++f)
     for (int k = 0; k < 7; ++k) acc += 0.0 * row[D->free_qadr[f] + k];
@@ -427,24 +451,24 @@ MK_DEV bool rest_nonfinite(const MkFusedDesc* __restrict__ D, const double* row)
 // cj.J is consumed (it becomes the weighted task Jacobian).  Returns the diagonal every dof
 // shares: damping plus the Levenberg-Marquardt terms.  `row` is the lane's q.
 template <int NC, bool REL>
-MK_DEV double assemble_chain_qp(const MkFusedDesc* __restrict__ D, const double* row, const double (&qc)[NC],
-                                ChainJac<NC>& cj, double dt, double damping, double (&c)[NC], double (&lo)[NC],
-                                double (&hi)[NC], double* hstore, int hstride, const MkFusedExt* __restrict__ X,
-                                Twist e_rel, double& hacc) {
+MK_DEV real assemble_chain_qp(const MkFusedDesc* __restrict__ D, const real* row, const real (&qc)[NC],
+                                ChainJac<NC>& cj, real dt, real damping, real (&c)[NC], real (&lo)[NC],
+                                real (&hi)[NC], real* hstore, int hstride, const MkFusedExt* __restrict__ X,
+                                Twist e_rel, real& hacc) {
   // second frame term (RelativeFrameTask, mink/tasks/relative_frame_task.py:106-142): its block of
   // H goes to the lane's LDS column first, its share of c and of the diagonal to registers
-  double c_rel[NC], diag_rel = 0.0;
+  real c_rel[NC], diag_rel = 0.0;
   if (REL) {
     M3 Jir, Bmr;
     se3_ljacinv_blocks(Twist{neg(e_rel.v), neg(e_rel.w)}, Jir, Bmr);   // jlog(T_rt^-1 T_rf) = ljacinv(-e)
-    double rc[6];
+    real rc[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) rc[r] = X->rel_cost[r];
     const int rs = X->rel_slot;
-    double Jr[6][NC];
+    real Jr[6][NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-      const double m = (k > rs) ? 1.0 : 0.0;   // joints in front of the root move root and frame alike
+      const real m = (k > rs) ? 1.0 : 0.0;   // joints in front of the root move root and frame alike
       const V3 bl = v3(cj.J[0][k], cj.J[1][k], cj.J[2][k]);
       const V3 ba = v3(cj.J[3][k], cj.J[4][k], cj.J[5][k]);
       const V3 tl = mul(Jir, bl) + mul(Bmr, ba);
@@ -452,8 +476,8 @@ MK_DEV double assemble_chain_qp(const MkFusedDesc* __restrict__ D, const double*
       Jr[0][k] = m * rc[0] * tl.x; Jr[1][k] = m * rc[1] * tl.y; Jr[2][k] = m * rc[2] * tl.z;
       Jr[3][k] = m * rc[3] * ta.x; Jr[4][k] = m * rc[4] * ta.y; Jr[5][k] = m * rc[5] * ta.z;
     }
-    const double gr = X->rel_gain;
-    const double ewr[6] = {rc[0] * (-gr * e_rel.v.x), rc[1] * (-gr * e_rel.v.y), rc[2] * (-gr * e_rel.v.z),
+    const real gr = X->rel_gain;
+    const real ewr[6] = {rc[0] * (-gr * e_rel.v.x), rc[1] * (-gr * e_rel.v.y), rc[2] * (-gr * e_rel.v.z),
                            rc[3] * (-gr * e_rel.w.x), rc[4] * (-gr * e_rel.w.y), rc[5] * (-gr * e_rel.w.z)};
     diag_rel = X->rel_lm * (ewr[0] * ewr[0] + ewr[1] * ewr[1] + ewr[2] * ewr[2] + ewr[3] * ewr[3] + ewr[4] * ewr[4] +
                             ewr[5] * ewr[5]);
@@ -461,12 +485,12 @@ MK_DEV double assemble_chain_qp(const MkFusedDesc* __restrict__ D, const double*
     for (int i = 0; i < NC; ++i) {
 #pragma unroll
       for (int j = 0; j <= i; ++j) {
-        double sr = 0.0;
+        real sr = 0.0;
 #pragma unroll
         for (int r = 0; r < 6; ++r) sr += Jr[r][i] * Jr[r][j];
         hstore[tri(i, j) * hstride] = sr;
       }
-      double sr = 0.0;
+      real sr = 0.0;
 #pragma unroll
       for (int r = 0; r < 6; ++r) sr += ewr[r] * Jr[r][i];
       c_rel[i] = -sr;
@@ -476,11 +500,11 @@ MK_DEV double assemble_chain_qp(const MkFusedDesc* __restrict__ D, const double*
   const Twist e = cj.e;
   M3 Ji, Bm;
   se3_ljacinv_blocks(e, Ji, Bm);
-  double cost[6];
+  real cost[6];
 #pragma unroll
   for (int r = 0; r < 6; ++r) cost[r] = D->cost[r];
   // Jw = diag(cost) (-jlog) J_b, in place (frame_task.py:146, task.py:125-127)
-  double (&Jw)[6][NC] = cj.J;
+  real (&Jw)[6][NC] = cj.J;
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     const V3 bl = v3(Jw[0][k], Jw[1][k], Jw[2][k]);
@@ -490,10 +514,10 @@ MK_DEV double assemble_chain_qp(const MkFusedDesc* __restrict__ D, const double*
     Jw[0][k] = -cost[0] * tl.x; Jw[1][k] = -cost[1] * tl.y; Jw[2][k] = -cost[2] * tl.z;
     Jw[3][k] = -cost[3] * ta.x; Jw[4][k] = -cost[4] * ta.y; Jw[5][k] = -cost[5] * ta.z;
   }
-  const double g = D->gain;
-  double ew[6] = {cost[0] * (-g * e.v.x), cost[1] * (-g * e.v.y), cost[2] * (-g * e.v.z),
+  const real g = D->gain;
+  real ew[6] = {cost[0] * (-g * e.v.x), cost[1] * (-g * e.v.y), cost[2] * (-g * e.v.z),
                   cost[3] * (-g * e.w.x), cost[4] * (-g * e.w.y), cost[5] * (-g * e.w.z)};
-  double diag = damping + D->lm * (ew[0] * ew[0] + ew[1] * ew[1] + ew[2] * ew[2] + ew[3] * ew[3] +
+  real diag = damping + D->lm * (ew[0] * ew[0] + ew[1] * ew[1] + ew[2] * ew[2] + ew[3] * ew[3] +
                                    ew[4] * ew[4] + ew[5] * ew[5]);
   if (REL) diag += diag_rel;
   // Levenberg-Marquardt terms of posture tasks need the error over every dof (rare).
@@ -501,10 +525,10 @@ MK_DEV double assemble_chain_qp(const MkFusedDesc* __restrict__ D, const double*
     for (int t = 0; t < D->nposture; ++t) {
       const MkPosture& P = D->posture[t];
       if (P.lm > 0.0) {
-        double s2 = 0.0;
+        real s2 = 0.0;
         for (int i = 0; i < D->nv; ++i) {
           if (D->dof[i].kind != MK_DOF_SCALAR) continue;
-          double ewi = P.cost[i] * (-P.gain * (P.target[i] - row[D->dof[i].qadr]));
+          real ewi = P.cost[i] * (-P.gain * (P.target[i] - row[D->dof[i].qadr]));
           s2 += ewi * ewi;
         }
         diag += P.lm * s2;
@@ -520,7 +544,7 @@ MK_DEV double assemble_chain_qp(const MkFusedDesc* __restrict__ D, const double*
     const MkDofC nx = D->sdof[i + 1 < NC ? i + 1 : i];   // requested one slot ahead
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
-      double s = 0.0;
+      real s = 0.0;
 #pragma unroll
       for (int r = 0; r < 6; ++r) s += Jw[r][i] * Jw[r][j];
       if (j == i) s += diag + dc.W;
@@ -533,12 +557,12 @@ MK_DEV double assemble_chain_qp(const MkFusedDesc* __restrict__ D, const double*
       hstore[tri(i, j) * hstride] = s;
 #endif
     }
-    double s = 0.0;
+    real s = 0.0;
 #pragma unroll
     for (int r = 0; r < 6; ++r) s += ew[r] * Jw[r][i];
     c[i] = dc.B * qc[i] - dc.A - s;
     if (REL) c[i] += c_rel[i];
-    const double vb = dt * dc.vmax;
+    const real vb = dt * dc.vmax;
     hi[i] = fmin(dc.gain * (dc.upper - qc[i]), vb);
     lo[i] = fmax(-(dc.gain * (qc[i] - dc.lower)), -vb);
     MK_SCHED_FENCE();
@@ -555,14 +579,14 @@ MK_DEV double assemble_chain_qp(const MkFusedDesc* __restrict__ D, const double*
 //   INTEGRATE == true : row[qadr] <- q (+) dt v for every non-chain dof, and their
 //                       velocity goes to vrow[dof] when vrow is not null
 template <int NC, bool INTEGRATE, bool REL = false>
-MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const double (&qc)[NC],
-                         ChainJac<NC>& cj, double dt, double inv_dt, double damping, double (&x)[NC],
-                         double* vrow, uint32_t& act, uint32_t& upper, bool warm, double* hstore,
+MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, real* row, const real (&qc)[NC],
+                         ChainJac<NC>& cj, real dt, real inv_dt, real damping, real (&x)[NC],
+                         double* vrow, uint32_t& act, uint32_t& upper, bool warm, real* hstore,
                          int hstride, bool input_bad = false, const MkFusedExt* __restrict__ X = nullptr,
                          Twist e_rel = Twist{V3{0, 0, 0}, V3{0, 0, 0}}) {
-  double c[NC], lo[NC], hi[NC];
-  double hacc = 0.0;
-  const double diag = assemble_chain_qp<NC, REL>(D, row, qc, cj, dt, damping, c, lo, hi, hstore, hstride, X, e_rel, hacc);
+  real c[NC], lo[NC], hi[NC];
+  real hacc = 0.0;
+  const real diag = assemble_chain_qp<NC, REL>(D, row, qc, cj, dt, damping, c, lo, hi, hstore, hstride, X, e_rel, hacc);
   MkDofC dc;
 
 #if defined(MK_ABLATE) && MK_ABLATE == 2
@@ -583,7 +607,8 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
     // (also: damping = 0 with a vanishing Levenberg-Marquardt term leaves the dofs that carry
     // no task cost with a zero Hessian entry -- the reference's QP backend rejects such a
     // singular P, mink/solve_ik.py:101-103)
-    if (input_bad || !(fabs(diag + c[0]) < INFINITY) || (D->needs_diag && !(diag > 0.0))) {
+    // (float32 build also: the solver lost a pivot of the factorisation to rounding)
+    if (input_bad || !(fabs(diag + c[0]) < INFINITY) || (D->needs_diag && !(diag > 0.0)) || (MK_IS_F32 && status == 3)) {
       status = 3;
 #pragma unroll
       for (int i = 0; i < NC; ++i) x[i] = 0.0;
@@ -603,16 +628,16 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
   } else
   for (int d = 0; d < nd; ++d) {
     const MkDofC nx = D->ddof[d + 1 < MK_MAX_NV ? d + 1 : d];
-    const double qi = row[dc.qadr];
-    const double vb = dt * dc.vmax;
-    const double h = fmin(dc.gain * (dc.upper - qi), vb);
-    const double l = fmax(-(dc.gain * (qi - dc.lower)), -vb);
+    const real qi = row[dc.qadr];
+    const real vb = dt * dc.vmax;
+    const real h = fmin(dc.gain * (dc.upper - qi), vb);
+    const real l = fmax(-(dc.gain * (qi - dc.lower)), -vb);
     if (!(l <= h)) status = 2;
-    const double xi = fmin(fmax(-(dc.B * qi - dc.A) * mk_rcp(diag + dc.W), l), h);
-    const double vi = xi * inv_dt;
+    const real xi = fmin(fmax(-(dc.B * qi - dc.A) * mk_rcp(diag + dc.W), l), h);
+    const real vi = xi * inv_dt;
     if (INTEGRATE) {
       row[dc.qadr] = qi + dt * vi;
-      if (vrow) vrow[dc.dof] = vi;
+      if (vrow) vrow[dc.dof] = (double)vi;
     } else {
       row[dc.dof] = vi;
     }
@@ -627,7 +652,7 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
   if (INTEGRATE) {
     // mj_integratePos renormalises free-joint quaternions even at zero velocity.
     for (int f = 0; f < D->nfree; ++f) {
-      double* qq = row + D->free_qadr[f] + 3;
+      real* qq = row + D->free_qadr[f] + 3;
       Q4 nq = qnormalize(Q4{qq[0], qq[1], qq[2], qq[3]});
       qq[0] = nq.w; qq[1] = nq.x; qq[2] = nq.y; qq[3] = nq.z;
     }
@@ -637,13 +662,13 @@ MK_DEV int solve_problem(const MkFusedDesc* __restrict__ D, double* row, const d
 
 // Coalesced copy between a [rows, width] global block and the per-lane LDS rows.
 template <bool TO_LDS>
-MK_DEV void tile_copy(double* tile, int stride, double* g, int rows, int width) {
+MK_DEV void tile_copy(real* tile, int stride, double* g, int rows, int width) {
   const int lane = threadIdx.x;
   int r = lane / width, cidx = lane % width;
   const int dr = 64 / width, dc = 64 % width;
   const int total = rows * width;
   for (int i = lane; i < total; i += 64) {
-    if (TO_LDS) tile[r * stride + cidx] = g[i]; else g[i] = tile[r * stride + cidx];
+    if (TO_LDS) tile[r * stride + cidx] = g[i]; else g[i] = (double)tile[r * stride + cidx];
     r += dr;
     cidx += dc;
     if (cidx >= width) { cidx -= width; ++r; }
@@ -654,20 +679,20 @@ template <int NC>
 __global__ MK_KERNEL_ATTR void fused_step_kernel(const MkFusedDesc* __restrict__ D,
                                                         const double* __restrict__ q,
                                                         const double* __restrict__ targets, int target_stride,
-                                                        double dt, double damping, int B,
+                                                        real dt, real damping, int B,
                                                         double* __restrict__ v_out, int32_t* __restrict__ status_out) {
-  extern __shared__ double tile[];
+  extern __shared__ real tile[];
   const int nq = D->nq, nv = D->nv;
   const int stride = nq | 1;
-  const double inv_dt = 1.0 / dt;
+  const real inv_dt = 1.0 / dt;
   const int lane = threadIdx.x;
   const long base = (long)blockIdx.x * 64;
   const int rows = (int)min((long)64, (long)B - base);
   tile_copy<true>(tile, stride, const_cast<double*>(q) + base * nq, rows, nq);
   __syncthreads();
   const bool valid = lane < rows;
-  double* row = tile + lane * stride;
-  double* hlds = tile + 64 * stride + lane;   // packed Hessian, element e at hlds[e * 64]
+  real* row = tile + lane * stride;
+  real* hlds = tile + 64 * stride + lane;   // packed Hessian, element e at hlds[e * 64]
   if (!valid) {
     for (int i = 0; i < nq; ++i) row[i] = tile[i];
   }
@@ -675,7 +700,7 @@ __global__ MK_KERNEL_ATTR void fused_step_kernel(const MkFusedDesc* __restrict__
   const double* tg = targets + pb * target_stride + D->target_off;
   Q4 Qt = Q4{tg[0], tg[1], tg[2], tg[3]};
   V3 pt = v3(tg[4], tg[5], tg[6]);
-  double qc[NC], x[NC];
+  real qc[NC], x[NC];
   load_chain_q<NC>(D, row, qc);
   ChainJac<NC> cj;
   chain_jac<NC>(D, qc, Qt, pt, cj);
@@ -690,6 +715,7 @@ __global__ MK_KERNEL_ATTR void fused_step_kernel(const MkFusedDesc* __restrict__
   tile_copy<false>(tile, stride, v_out + base * nv, rows, nv);
 }
 
+#if !defined(MK_F32)
 // Pose composition helpers of the collision screen.
 struct PoseQT {
   Q4 q;
@@ -699,13 +725,13 @@ MK_DEV PoseQT pose_then(PoseQT a, Q4 bq, V3 bt) { return PoseQT{qmul(a.q, bq), a
 
 // World pose of the frame behind chain joint `slot` (forward composition of the canonical
 // segments 0..slot at the lane's q): where a collision body on an inner link of the chain hangs.
-MK_DEV PoseQT chain_frame_pose(const MkFusedDesc* __restrict__ D, const double* row, int slot) {
+MK_DEV PoseQT chain_frame_pose(const MkFusedDesc* __restrict__ D, const real* row, int slot) {
   PoseQT p = PoseQT{Q4{1, 0, 0, 0}, v3(0, 0, 0)};
   for (int i = 0; i <= slot; ++i) {
     const MkSegC& S = D->segc[i];
     p = pose_then(p, Q4{S.pq[0], S.pq[1], S.pq[2], S.pq[3]}, v3(S.pp[0], S.pp[1], S.pp[2]));
-    const double qv = D->seg_dof[i] >= 0 ? row[D->seg_qadr[i]] : 0.0;
-    double sn, cs;
+    const real qv = D->seg_dof[i] >= 0 ? row[D->seg_qadr[i]] : 0.0;
+    real sn, cs;
     mk_sincos(0.5 * (S.hinge * qv), &sn, &cs);
     p = pose_then(p, Q4{cs, 0.0, 0.0, sn}, v3(0.0, 0.0, S.slide * qv));
   }
@@ -718,8 +744,8 @@ MK_DEV PoseQT chain_frame_pose(const MkFusedDesc* __restrict__ D, const double* 
 // behind which the general kernel skips a pair, so a problem that passes has no finite
 // collision row there either.  (Qw, tw) is the world pose of the task frame, `row` the
 // lane's q.
-MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const double* row,
-                               Q4 Qw, V3 tw, double* scr, int ss) {
+MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const real* row,
+                               Q4 Qw, V3 tw, real* scr, int ss) {
   // frame behind the chain's last joint: task frame o post^-1
   const Q4 postq = Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]};
   PoseQT tip;
@@ -736,13 +762,13 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
       for (int sidx = 0; sidx < CB.nseg; ++sidx) {
         const MkCollSeg& S = CB.seg[sidx];
         p = pose_then(p, Q4{S.pq[0], S.pq[1], S.pq[2], S.pq[3]}, v3(S.pp[0], S.pp[1], S.pp[2]));
-        const double qv = row[S.qadr];
-        double sn, cs;
+        const real qv = row[S.qadr];
+        real sn, cs;
         mk_sincos(0.5 * (S.hinge * qv), &sn, &cs);
         p = pose_then(p, Q4{cs, 0.0, 0.0, sn}, v3(0.0, 0.0, S.slide * qv));
       }
     } else if (CB.kind == MK_CB_FREE) {
-      const double* f = row + CB.free_qadr;
+      const real* f = row + CB.free_qadr;
       p.t = v3(f[0], f[1], f[2]);
       p.q = qnormalize(Q4{f[3], f[4], f[5], f[6]});
     }
@@ -751,10 +777,10 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
       const MkCollGeom& G = X->cgeom[g];
       const PoseQT w = pose_then(p, Q4{G.lq[0], G.lq[1], G.lq[2], G.lq[3]}, v3(G.lp[0], G.lp[1], G.lp[2]));
       const V3 c = w.t + qrot(w.q, v3(G.bc[0], G.bc[1], G.bc[2]));
-      double* sc = scr + 3 * g * ss;
+      real* sc = scr + 3 * g * ss;
       sc[0] = c.x; sc[ss] = c.y; sc[2 * ss] = c.z;
       if (G.oslot >= 0) {
-        double* so = scr + (3 * ng + 4 * G.oslot) * ss;
+        real* so = scr + (3 * ng + 4 * G.oslot) * ss;
         so[0] = w.q.w; so[ss] = w.q.x; so[2 * ss] = w.q.y; so[3 * ss] = w.q.z;
       }
     }
@@ -763,26 +789,26 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
   const int np = X->ncpair;
   for (int k = 0; k < np; ++k) {
     const int g1 = X->cpair[k].g1, g2 = X->cpair[k].g2;
-    const double d_detect = X->cpair[k].d_detect;
+    const real d_detect = X->cpair[k].d_detect;
     const MkCollGeom& G1 = X->cgeom[g1];
     const MkCollGeom& G2 = X->cgeom[g2];
     // centres of the bounding spheres (the geom centre but for meshes); orientations where kept
-    const double *s1 = scr + 3 * g1 * ss, *s2 = scr + 3 * g2 * ss;
+    const real *s1 = scr + 3 * g1 * ss, *s2 = scr + 3 * g2 * ss;
     const V3 ac = v3(s1[0], s1[ss], s1[2 * ss]), bcw = v3(s2[0], s2[ss], s2[2 * ss]);
     PoseQT a = PoseQT{Q4{1, 0, 0, 0}, ac}, b = PoseQT{Q4{1, 0, 0, 0}, bcw};
     if (G1.oslot >= 0) {
-      const double* so = scr + (3 * ng + 4 * G1.oslot) * ss;
+      const real* so = scr + (3 * ng + 4 * G1.oslot) * ss;
       a.q = Q4{so[0], so[ss], so[2 * ss], so[3 * ss]};
     }
     if (G2.oslot >= 0) {
-      const double* so = scr + (3 * ng + 4 * G2.oslot) * ss;
+      const real* so = scr + (3 * ng + 4 * G2.oslot) * ss;
       b.q = Q4{so[0], so[ss], so[2 * ss], so[3 * ss]};
     }
-    double lower;
+    real lower;
     if (G1.type == 0) {   // plane: height of the other geom's centre minus its extent along the normal
       const M3 R1 = q2m(a.q);
       const V3 n = v3(R1.m[2], R1.m[5], R1.m[8]);
-      double ext = G2.rbound;
+      real ext = G2.rbound;
       if (G2.type == 6) {
         const M3 R2 = q2m(b.q);
         const V3 nl = mulT(R2, n);
@@ -796,7 +822,7 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
         // two boxes: the largest gap along the 15 candidate separating axes
         const M3 R1 = q2m(a.q), R2 = q2m(b.q);
         const V3 h1 = v3(G1.size[0], G1.size[1], G1.size[2]), h2 = v3(G2.size[0], G2.size[1], G2.size[2]);
-        double gap = -INFINITY;
+        real gap = -INFINITY;
 #pragma unroll
         for (int ax = 0; ax < 15; ++ax) {
           V3 u;
@@ -806,12 +832,12 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
             const int i = (ax - 6) / 3, j = (ax - 6) % 3;
             u = cross(v3(R1.m[i], R1.m[3 + i], R1.m[6 + i]), v3(R2.m[j], R2.m[3 + j], R2.m[6 + j]));
           }
-          const double n2 = dot(u, u);
+          const real n2 = dot(u, u);
           if (n2 >= 1e-12) {
             u = (1.0 / sqrt(n2)) * u;
             const V3 a1 = mulT(R1, u), a2 = mulT(R2, u);
-            const double ra = fabs(a1.x) * h1.x + fabs(a1.y) * h1.y + fabs(a1.z) * h1.z;
-            const double rb = fabs(a2.x) * h2.x + fabs(a2.y) * h2.y + fabs(a2.z) * h2.z;
+            const real ra = fabs(a1.x) * h1.x + fabs(a1.y) * h1.y + fabs(a1.z) * h1.z;
+            const real rb = fabs(a2.x) * h2.x + fabs(a2.y) * h2.y + fabs(a2.z) * h2.z;
             gap = fmax(gap, fabs(dot(d, u)) - ra - rb);
           }
         }
@@ -827,14 +853,14 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
 // CollisionAvoidanceLimit rows of one lane's problem: row k over all nv dofs, element
 // (k, dof) at g[(k * nv + dof) * stride] (the lane's LDS column on the GPU), bound h[k].
 struct LaneRows {
-  double* g;
+  real* g;
   int stride, nv, n;
-  double h[MK_LANE_ROWS];
-  MK_DEV double& at(int k, int dof) const { return g[(k * nv + dof) * stride]; }
+  real h[MK_LANE_ROWS];
+  MK_DEV real& at(int k, int dof) const { return g[(k * nv + dof) * stride]; }
 };
 
 // World pose of collision body b; `tip` is the frame behind the chain's last joint.
-MK_DEV PoseQT coll_body_pose(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const double* row,
+MK_DEV PoseQT coll_body_pose(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const real* row,
                              PoseQT tip, int b) {
   const MkCollBody& CB = X->cbody[b];
   PoseQT p = PoseQT{Q4{1, 0, 0, 0}, v3(0, 0, 0)};
@@ -843,13 +869,13 @@ MK_DEV PoseQT coll_body_pose(const MkFusedDesc* __restrict__ D, const MkFusedExt
     for (int sidx = 0; sidx < CB.nseg; ++sidx) {
       const MkCollSeg& S = CB.seg[sidx];
       p = pose_then(p, Q4{S.pq[0], S.pq[1], S.pq[2], S.pq[3]}, v3(S.pp[0], S.pp[1], S.pp[2]));
-      const double qv = row[S.qadr];
-      double sn, cs;
+      const real qv = row[S.qadr];
+      real sn, cs;
       mk_sincos(0.5 * (S.hinge * qv), &sn, &cs);
       p = pose_then(p, Q4{cs, 0.0, 0.0, sn}, v3(0.0, 0.0, S.slide * qv));
     }
   } else if (CB.kind == MK_CB_FREE) {
-    const double* f = row + CB.free_qadr;
+    const real* f = row + CB.free_qadr;
     p.t = v3(f[0], f[1], f[2]);
     p.q = qnormalize(Q4{f[3], f[4], f[5], f[6]});
   }
@@ -862,8 +888,8 @@ MK_DEV PoseQT coll_body_pose(const MkFusedDesc* __restrict__ D, const MkFusedExt
 // the task frame (J, still unweighted; task frame at (tw, Rw)) gives the motion of every point
 // behind a joint: n' Rw (v_j + w_j x r) = (Rw'n).v_j + (r x Rw'n).w_j with r = Rw'(point - tw).
 template <int NC>
-MK_DEV void add_point_row(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const double* row,
-                          const double (&J)[6][NC], V3 tw, const M3& Rw, PoseQT tip, int b, V3 point, V3 n, double s,
+MK_DEV void add_point_row(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const real* row,
+                          const real (&J)[6][NC], V3 tw, const M3& Rw, PoseQT tip, int b, V3 point, V3 n, real s,
                           const LaneRows& R, int m) {
   const MkCollBody& CB = X->cbody[b];
   if (CB.kind == MK_CB_TIP) {
@@ -874,7 +900,7 @@ MK_DEV void add_point_row(const MkFusedDesc* __restrict__ D, const MkFusedExt* _
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const int dof = D->seg_dof[j];
-      const double val = nt.x * J[0][j] + nt.y * J[1][j] + nt.z * J[2][j] + mt.x * J[3][j] + mt.y * J[4][j] + mt.z * J[5][j];
+      const real val = nt.x * J[0][j] + nt.y * J[1][j] + nt.z * J[2][j] + mt.x * J[3][j] + mt.y * J[4][j] + mt.z * J[5][j];
       if (dof >= 0 && j <= CB.slot) R.at(m, dof) += s * val;
     }
     PoseQT f = CB.slot >= D->nc - 1 ? tip : chain_frame_pose(D, row, CB.slot);
@@ -882,16 +908,16 @@ MK_DEV void add_point_row(const MkFusedDesc* __restrict__ D, const MkFusedExt* _
       const MkCollSeg& S = CB.seg[sidx];
       f = pose_then(f, Q4{S.pq[0], S.pq[1], S.pq[2], S.pq[3]}, v3(S.pp[0], S.pp[1], S.pp[2]));
       const V3 z = qrot(f.q, v3(0, 0, 1));
-      const double val = S.hinge * dot(n, cross(z, point - f.t)) + S.slide * dot(n, z);
+      const real val = S.hinge * dot(n, cross(z, point - f.t)) + S.slide * dot(n, z);
       R.at(m, S.dof) += s * val;
-      const double qv = row[S.qadr];
-      double sn, cs;
+      const real qv = row[S.qadr];
+      real sn, cs;
       mk_sincos(0.5 * (S.hinge * qv), &sn, &cs);
       f = pose_then(f, Q4{cs, 0.0, 0.0, sn}, v3(0.0, 0.0, S.slide * qv));
     }
   } else if (CB.kind == MK_CB_FREE) {
     // free joint: translation along the world axes, rotation about the body's own axes
-    const double* fq = row + CB.free_qadr;
+    const real* fq = row + CB.free_qadr;
     const M3 Rb = q2m(qnormalize(Q4{fq[3], fq[4], fq[5], fq[6]}));
     const V3 w = mulT(Rb, cross(point - v3(fq[0], fq[1], fq[2]), n));
     const int d0 = CB.free_dofadr;
@@ -907,8 +933,8 @@ MK_DEV void add_point_row(const MkFusedDesc* __restrict__ D, const MkFusedExt* _
 // the lane form cannot hold the problem: more than MK_LANE_ROWS rows in range, or a pair without a
 // closed form (ellipsoid, cylinder, mesh) that may be in range.
 template <int NC>
-MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const double* row,
-                           const double (&J)[6][NC], Q4 Qw, V3 tw, const M3& Rw, double dt, LaneRows& R) {
+MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const real* row,
+                           const real (&J)[6][NC], Q4 Qw, V3 tw, const M3& Rw, real dt, LaneRows& R) {
   const Q4 postq = Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]};
   PoseQT tip;
   tip.q = qmul(Qw, qconj(postq));
@@ -939,7 +965,7 @@ MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* 
     const V3 s2 = v3(G2.size[0], G2.size[1], G2.size[2]);
     // bounding spheres first (the bound behind which the general kernel skips the pair, too)
     const V3 bcw = b.t + qrot(b.q, v3(G2.bc[0], G2.bc[1], G2.bc[2]));
-    double lower;
+    real lower;
     if (G1.type == 0) {
       lower = dot(bcw - a.t, col(R1, 2)) - G2.rbound;
     } else {
@@ -957,9 +983,9 @@ MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* 
     if (R.n >= MK_LANE_ROWS) { ok = false; continue; }
     const int m = R.n++;
     const V3 dn = ct.p2 - ct.p1;
-    const double nn = sqrt(dot(dn, dn));
+    const real nn = sqrt(dot(dn, dn));
     const V3 nrm = nn < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nn) * dn;
-    const double hval = ct.dist > P.d_min ? P.gain * (ct.dist - P.d_min) / dt + P.relax : P.relax;
+    const real hval = ct.dist > P.d_min ? P.gain * (ct.dist - P.d_min) / dt + P.relax : P.relax;
 #pragma unroll
     for (int i = 0; i < MK_LANE_ROWS; ++i)
       if (i == m) R.h[i] = hval;
@@ -988,34 +1014,34 @@ MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* 
 // in kOuter steps to the general kernel.
 // Returns true with x (chain dofs) and the other dofs' dq in vrow[dof] (already divided by dt).
 template <int NC>
-MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView H, const double (&c)[NC],
-                    const double (&lo)[NC], const double (&hi)[NC], double diag, double dt, double inv_dt,
-                    const LaneRows& R, double (&x)[NC], double* vrow) {
+MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const real* row, HView H, const real (&c)[NC],
+                    const real (&lo)[NC], const real (&hi)[NC], real diag, real dt, real inv_dt,
+                    const LaneRows& R, real (&x)[NC], real* vrow) {
   constexpr int M = MK_LANE_ROWS;
   constexpr int kOuter = 16;
-  constexpr double kTol = 1e-13;
-  double mu[M], mu_prev[M], merit_prev = INFINITY;
+  constexpr real kTol = 1e-13;
+  real mu[M], mu_prev[M], merit_prev = INFINITY;
 #pragma unroll
   for (int k = 0; k < M; ++k) mu[k] = mu_prev[k] = 0.0;
   uint32_t act = 0u, upper = 0u;
   bool done = false, good = false;
   const int nd = D->nd, nrows = R.n;
-  const double rdiag = mk_rcp(diag);
+  const real rdiag = mk_rcp(diag);
   for (int it = 0; it < kOuter; ++it) {
     if (!done) {
       // ---- box problem at mu ----
-      double cm[NC];
+      real cm[NC];
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
         const int dof = D->seg_dof[i];
-        double sft = 0.0;
+        real sft = 0.0;
 #pragma unroll
         for (int k = 0; k < M; ++k) sft += mu[k] * R.at(k, dof >= 0 ? dof : 0);
         cm[i] = c[i] + (dof >= 0 ? sft : 0.0);
       }
       asm volatile("" ::: "memory");
       const int st = box_qp<NC>(H, cm, lo, hi, x, act, upper, it > 0);
-      double r[M];
+      real r[M];
 #pragma unroll
       for (int k = 0; k < M; ++k) r[k] = k < nrows ? -R.h[k] : 0.0;
 #pragma unroll
@@ -1028,16 +1054,16 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
       bool infeasible = st != 0;
       for (int d = 0; d < nd; ++d) {
         const MkDofC dc = D->ddof[d];
-        const double qi = row[dc.qadr];
-        const double vb = dt * dc.vmax;
-        const double h = fmin(dc.gain * (dc.upper - qi), vb);
-        const double l = fmax(-(dc.gain * (qi - dc.lower)), -vb);
+        const real qi = row[dc.qadr];
+        const real vb = dt * dc.vmax;
+        const real h = fmin(dc.gain * (dc.upper - qi), vb);
+        const real l = fmax(-(dc.gain * (qi - dc.lower)), -vb);
         infeasible |= !(l <= h);
-        double g[M], sft = 0.0;
+        real g[M], sft = 0.0;
 #pragma unroll
         for (int k = 0; k < M; ++k) { g[k] = R.at(k, dc.dof); sft += mu[k] * g[k]; }
-        const double raw = -(dc.B * qi - dc.A + sft) * mk_rcp(diag + dc.W);
-        const double y = fmin(fmax(raw, l), h);
+        const real raw = -(dc.B * qi - dc.A + sft) * mk_rcp(diag + dc.W);
+        const real y = fmin(fmax(raw, l), h);
         if (raw < l || raw > h) clamped |= 1ull << d;
 #pragma unroll
         for (int k = 0; k < M; ++k) r[k] += g[k] * y;
@@ -1046,10 +1072,10 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
       for (int f = 0; f < D->nfree; ++f) {
         for (int j = 0; j < 6; ++j) {
           const int dof = D->free_dofadr[f] + j;
-          double g[M], sft = 0.0;
+          real g[M], sft = 0.0;
 #pragma unroll
           for (int k = 0; k < M; ++k) { g[k] = R.at(k, dof); sft += mu[k] * g[k]; }
-          const double z = -sft * rdiag;
+          const real z = -sft * rdiag;
 #pragma unroll
           for (int k = 0; k < M; ++k) r[k] += g[k] * z;
           vrow[dof] = z * inv_dt;
@@ -1059,14 +1085,14 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
       bool kkt = true;
 #pragma unroll
       for (int k = 0; k < M; ++k) {
-        const double tol = kTol * fmax(1.0, fabs(R.h[k]));
+        const real tol = kTol * fmax(1.0, fabs(R.h[k]));
         if (k < nrows) kkt &= (mu[k] > 0.0) ? (fabs(r[k]) <= tol) : (r[k] <= tol);
       }
       // natural residual of the rows' complementarity conditions: the step control's merit
-      double merit = 0.0;
+      real merit = 0.0;
 #pragma unroll
       for (int k = 0; k < M; ++k) {
-        const double rho = fmin(mu[k], -r[k]);
+        const real rho = fmin(mu[k], -r[k]);
         if (k < nrows) merit += rho * rho;
       }
       if (infeasible) {
@@ -1083,17 +1109,17 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
 #pragma unroll
         for (int k = 0; k < M; ++k) mu_prev[k] = mu[k];
         // ---- S on the current piece ----
-        double L[NC * (NC + 1) / 2], Ld[NC];
+        real L[NC * (NC + 1) / 2], Ld[NC];
         asm volatile("" ::: "memory");
         chol_masked<NC>(H, act, L, Ld);
-        double S[M][M];
+        real S[M][M];
 #pragma unroll
         for (int k = 0; k < M; ++k)
 #pragma unroll
           for (int l = 0; l < M; ++l) S[k][l] = 0.0;
 #pragma unroll
         for (int k = 0; k < M; ++k) {
-          double sk[NC];
+          real sk[NC];
 #pragma unroll
           for (int i = 0; i < NC; ++i) {
             const int dof = D->seg_dof[i];
@@ -1111,8 +1137,8 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
         }
         for (int d = 0; d < nd; ++d) {
           const MkDofC dc = D->ddof[d];
-          const double iw = ((clamped >> d) & 1ull) ? 0.0 : mk_rcp(diag + dc.W);
-          double g[M];
+          const real iw = ((clamped >> d) & 1ull) ? 0.0 : mk_rcp(diag + dc.W);
+          real g[M];
 #pragma unroll
           for (int k = 0; k < M; ++k) g[k] = R.at(k, dc.dof);
 #pragma unroll
@@ -1124,7 +1150,7 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
         for (int f = 0; f < D->nfree; ++f) {
           for (int j = 0; j < 6; ++j) {
             const int dof = D->free_dofadr[f] + j;
-            double g[M];
+            real g[M];
 #pragma unroll
             for (int k = 0; k < M; ++k) g[k] = R.at(k, dof);
 #pragma unroll
@@ -1139,7 +1165,7 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
 #pragma unroll
           for (int l = 0; l < k; ++l) S[k][l] = S[l][k];
         // ---- complementarity problem of the piece: mu' >= 0, w = S mu' - b >= 0, mu'.w = 0 ----
-        double b[M];
+        real b[M];
 #pragma unroll
         for (int k = 0; k < M; ++k) {
           b[k] = r[k];
@@ -1147,7 +1173,7 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
           for (int l = 0; l < M; ++l) b[k] += S[k][l] * mu[l];
         }
         bool found = false;
-        double best[M];
+        real best[M];
 #pragma unroll
         for (int k = 0; k < M; ++k) best[k] = 0.0;
         // the sets are tried starting from the likely one -- the rows that carry a multiplier or are
@@ -1161,7 +1187,7 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
           if (found || (trial >> nrows) != 0) continue;
           const int w = trial ^ w0;
           // rows outside the set: unit row / column, zero right-hand side
-          double A[M][M], rhs[M];
+          real A[M][M], rhs[M];
 #pragma unroll
           for (int k = 0; k < M; ++k) {
             const bool ink = (w >> k) & 1;
@@ -1173,19 +1199,19 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
             }
           }
           // Cholesky solve of the masked (symmetric positive definite) system
-          double Lc[M][M], m3[M];
+          real Lc[M][M], m3[M];
           bool spd = true;
 #pragma unroll
           for (int j = 0; j < M; ++j) {
-            double dj = A[j][j];
+            real dj = A[j][j];
 #pragma unroll
             for (int k = 0; k < j; ++k) dj -= Lc[j][k] * Lc[j][k];
             spd &= dj > 1e-12 * A[j][j];   // dependent rows on this piece
-            const double rj = 1.0 / sqrt(fmax(dj, 1e-300));
+            const real rj = 1.0 / sqrt(fmax(dj, MK_TINY));
             Lc[j][j] = rj;
 #pragma unroll
             for (int i = j + 1; i < M; ++i) {
-              double t = A[i][j];
+              real t = A[i][j];
 #pragma unroll
               for (int k = 0; k < j; ++k) t -= Lc[i][k] * Lc[j][k];
               Lc[i][j] = t * rj;
@@ -1194,14 +1220,14 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
           if (!spd) continue;
 #pragma unroll
           for (int i = 0; i < M; ++i) {
-            double t = rhs[i];
+            real t = rhs[i];
 #pragma unroll
             for (int k = 0; k < i; ++k) t -= Lc[i][k] * m3[k];
             m3[i] = t * Lc[i][i];
           }
 #pragma unroll
           for (int i = M - 1; i >= 0; --i) {
-            double t = m3[i];
+            real t = m3[i];
 #pragma unroll
             for (int k = i + 1; k < M; ++k) t -= Lc[k][i] * m3[k];
             m3[i] = t * Lc[i][i];
@@ -1210,7 +1236,7 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
 #pragma unroll
           for (int k = 0; k < M; ++k) {
             const bool ink = (w >> k) & 1;
-            double wk = -b[k];
+            real wk = -b[k];
 #pragma unroll
             for (int l = 0; l < M; ++l) wk += S[k][l] * m3[l];
             if (ink) valid &= m3[k] >= 0.0;
@@ -1229,34 +1255,34 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
           // unconstrained value at the rate -G_kd / w_d (ratio test).  A little beyond that point
           // the box problem frees the dof and the next piece has curvature.
           asm volatile("" ::: "memory");
-          double hx[NC];
+          real hx[NC];
           symv<NC>(H, x, hx);
           int kstep = -1;
-          double worst = 0.0, tstep = 0.0;
+          real worst = 0.0, tstep = 0.0;
 #pragma unroll
           for (int k = 0; k < M; ++k) {
-            const double tol = kTol * fmax(1.0, fabs(R.h[k]));
-            double tau = INFINITY;
+            const real tol = kTol * fmax(1.0, fabs(R.h[k]));
+            real tau = INFINITY;
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
               const int dof = D->seg_dof[i];
-              const double gki = dof >= 0 ? R.at(k, dof) : 0.0;
+              const real gki = dof >= 0 ? R.at(k, dof) : 0.0;
               const bool up = (upper >> i) & 1u;
-              const double gi = cm[i] + hx[i];
-              const double ui = fmax(up ? -gi : gi, 0.0), slope = up ? -gki : gki;
+              const real gi = cm[i] + hx[i];
+              const real ui = fmax(up ? -gi : gi, 0.0), slope = up ? -gki : gki;
               if (((act >> i) & 1u) && slope < 0.0) tau = fmin(tau, ui / -slope);
             }
             for (int d = 0; d < nd; ++d) {
               const MkDofC dc = D->ddof[d];
-              const double qi = row[dc.qadr];
-              const double vb = dt * dc.vmax;
-              const double h = fmin(dc.gain * (dc.upper - qi), vb);
-              const double l = fmax(-(dc.gain * (qi - dc.lower)), -vb);
-              double sft = 0.0;
+              const real qi = row[dc.qadr];
+              const real vb = dt * dc.vmax;
+              const real h = fmin(dc.gain * (dc.upper - qi), vb);
+              const real l = fmax(-(dc.gain * (qi - dc.lower)), -vb);
+              real sft = 0.0;
 #pragma unroll
               for (int kk = 0; kk < M; ++kk) sft += mu[kk] * R.at(kk, dc.dof);
-              const double w = diag + dc.W, gkd = R.at(k, dc.dof);
-              const double raw = -(dc.B * qi - dc.A + sft) / w;
+              const real w = diag + dc.W, gkd = R.at(k, dc.dof);
+              const real raw = -(dc.B * qi - dc.A + sft) / w;
               if (raw > h && gkd > 0.0) tau = fmin(tau, (raw - h) * w / gkd);
               if (raw < l && gkd < 0.0) tau = fmin(tau, (l - raw) * w / -gkd);
             }
@@ -1288,13 +1314,13 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const double* row, HView 
 // (read in place), hstore / gstore the lane's columns for H and the rows.  Returns true when
 // vrow [nv] holds the problem's velocity; false leaves the problem to the general kernel.
 template <int NC>
-MK_DEV bool rows_problem(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const double* row,
-                         const double* tg_row, double dt, double inv_dt, double damping, double* vrow, double* hstore,
-                         int hstride, double* gstore, int gstride) {
-  const double* tg = tg_row + D->target_off;
+MK_DEV bool rows_problem(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const real* row,
+                         const real* tg_row, real dt, real inv_dt, real damping, real* vrow, real* hstore,
+                         int hstride, real* gstore, int gstride) {
+  const real* tg = tg_row + D->target_off;
   const Q4 Qt = Q4{tg[0], tg[1], tg[2], tg[3]};
   const V3 pt = v3(tg[4], tg[5], tg[6]);
-  double qc[NC], x[NC];
+  real qc[NC], x[NC];
   load_chain_q<NC>(D, row, qc);
   ChainJac<NC> cj;
   Q4 Qw, Qcap = Q4{1, 0, 0, 0};
@@ -1311,9 +1337,9 @@ MK_DEV bool rows_problem(const MkFusedDesc* __restrict__ D, const MkFusedExt* __
   for (int k = 0; k < MK_LANE_ROWS; ++k) R.h[k] = INFINITY;
   for (int i = 0; i < MK_LANE_ROWS * D->nv; ++i) gstore[i * gstride] = 0.0;
   const bool fits = collision_rows<NC>(D, X, row, cj.J, Qw, tw, Rw, dt, R);
-  double c[NC], lo[NC], hi[NC], hacc = 0.0, diag;
+  real c[NC], lo[NC], hi[NC], hacc = 0.0, diag;
   if (X->has_rel) {
-    const double* tr = tg_row + X->rel_target_off;
+    const real* tr = tg_row + X->rel_target_off;
     const Q4 Qrt = Q4{tr[0], tr[1], tr[2], tr[3]};
     const V3 prt = v3(tr[4], tr[5], tr[6]);
     const Q4 xqi = qconj(Q4{X->rel_xq[0], X->rel_xq[1], X->rel_xq[2], X->rel_xq[3]});
@@ -1345,16 +1371,16 @@ MK_DEV bool rows_problem(const MkFusedDesc* __restrict__ D, const MkFusedExt* __
 template <int NC>
 __global__ MK_KERNEL_ATTR void fused_rows_kernel(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X,
                                                  const double* __restrict__ q, const double* __restrict__ targets,
-                                                 int target_stride, double dt, double damping, int B,
+                                                 int target_stride, real dt, real damping, int B,
                                                  double* __restrict__ v_out, int32_t* status_out) {
-  extern __shared__ double tile[];
+  extern __shared__ real tile[];
   constexpr int NH = NC * (NC + 1) / 2;
   const int nq = D->nq, nv = D->nv;
   const int lane = threadIdx.x;
-  double* hlds = tile + lane;
-  double* glds = tile + NH * 64 + lane;
+  real* hlds = tile + lane;
+  real* glds = tile + NH * 64 + lane;
   int32_t* queue = reinterpret_cast<int32_t*>(tile + (NH + MK_LANE_ROWS * nv) * 64);   // 128 entries
-  const double inv_dt = 1.0 / dt;
+  const real inv_dt = 1.0 / dt;
   const int nchunks = (B + 63) / 64;
   int n = 0;
   for (int ch = blockIdx.x;; ch += gridDim.x) {
@@ -1401,22 +1427,22 @@ __global__ MK_KERNEL_ATTR void fused_step_ext_kernel(const MkFusedDesc* __restri
                                                      const MkFusedExt* __restrict__ X,
                                                      const double* __restrict__ q,
                                                      const double* __restrict__ targets, int target_stride,
-                                                     double dt, double damping, int B,
-                                                     double* v_out, int32_t* status_out, int32_t* iters,
+                                                     real dt, real damping, int B,
+                                                     real* v_out, int32_t* status_out, int32_t* iters,
                                                      double* __restrict__ err_out, int it, int max_iters,
-                                                     double pos_tol, double ori_tol) {
-  extern __shared__ double tile[];
+                                                     real pos_tol, real ori_tol) {
+  extern __shared__ real tile[];
   const int nq = D->nq, nv = D->nv;
   const int stride = nq | 1;
-  const double inv_dt = 1.0 / dt;
+  const real inv_dt = 1.0 / dt;
   const int lane = threadIdx.x;
   const long base = (long)blockIdx.x * 64;
   const int rows = (int)min((long)64, (long)B - base);
   tile_copy<true>(tile, stride, const_cast<double*>(q) + base * nq, rows, nq);
   __syncthreads();
   const bool valid = lane < rows;
-  double* row = tile + lane * stride;
-  double* hlds = tile + 64 * stride + lane;
+  real* row = tile + lane * stride;
+  real* hlds = tile + 64 * stride + lane;
   if (!valid) {
     for (int i = 0; i < nq; ++i) row[i] = tile[i];
   }
@@ -1424,7 +1450,7 @@ __global__ MK_KERNEL_ATTR void fused_step_ext_kernel(const MkFusedDesc* __restri
   const double* tg = targets + pb * target_stride + D->target_off;
   const Q4 Qt = Q4{tg[0], tg[1], tg[2], tg[3]};
   const V3 pt = v3(tg[4], tg[5], tg[6]);
-  double qc[NC], x[NC];
+  real qc[NC], x[NC];
   load_chain_q<NC>(D, row, qc);
   ChainJac<NC> cj;
   Q4 Qw, Qcap = Q4{1, 0, 0, 0};
@@ -1439,7 +1465,7 @@ __global__ MK_KERNEL_ATTR void fused_step_ext_kernel(const MkFusedDesc* __restri
     const bool conv = it > 0 && sqrt(dot(cj.e.v, cj.e.v)) <= pos_tol && sqrt(dot(cj.e.w, cj.e.w)) <= ori_tol;
     const bool done_now = conv || it == max_iters;
     if (valid && !was_done) {
-      double* eo = err_out + pb * 6;
+      real* eo = err_out + pb * 6;
       eo[0] = cj.e.v.x; eo[1] = cj.e.v.y; eo[2] = cj.e.v.z; eo[3] = cj.e.w.x; eo[4] = cj.e.w.y; eo[5] = cj.e.w.z;
       iters[pb] = done_now ? (cur | MK_ITER_DONE_BIT) : it + 1;
     }
@@ -1454,7 +1480,7 @@ __global__ MK_KERNEL_ATTR void fused_step_ext_kernel(const MkFusedDesc* __restri
   int status;
   if (X->has_rel) {
     // T_root,frame = X^-1 o (pose carried at the root's slot); e = log(T_rt^-1 T_rf)
-    const double* tr = targets + pb * target_stride + X->rel_target_off;
+    const real* tr = targets + pb * target_stride + X->rel_target_off;
     const Q4 Qrt = Q4{tr[0], tr[1], tr[2], tr[3]};
     const V3 prt = v3(tr[4], tr[5], tr[6]);
     bad |= !(fabs(tr[0] + tr[1] + tr[2] + tr[3] + tr[4] + tr[5] + tr[6]) < INFINITY);
@@ -1492,28 +1518,30 @@ __global__ MK_KERNEL_ATTR void fused_step_ext_kernel(const MkFusedDesc* __restri
 // problems of a wave finish at different iterations, and the last few would hold the launch for
 // their remaining sequential solves; the cooperative kernel (coop_resume_kernel, mk_coop.hip)
 // finishes them at 16 lanes per problem.
+#endif  // !MK_F32
+
 template <int NC, bool HANDOFF = false>
 __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restrict__ D_arg,
                                                            double* __restrict__ q,
                                                            const double* __restrict__ targets, int target_stride,
-                                                           double dt, double damping, int B, int max_iters,
-                                                           double pos_tol, double ori_tol,
+                                                           real dt, real damping, int B, int max_iters,
+                                                           real pos_tol, real ori_tol,
                                                            double* __restrict__ v_out, int32_t* __restrict__ iters_out,
                                                            double* __restrict__ err_out,
                                                            int32_t* __restrict__ status_out, int handoff_live = 0) {
   const MkFusedDesc* D = D_arg;
-  extern __shared__ double tile[];
+  extern __shared__ real tile[];
   const int nq = D->nq, nv = D->nv;
   const int stride = nq | 1;
-  const double inv_dt = 1.0 / dt;
+  const real inv_dt = 1.0 / dt;
   const int lane = threadIdx.x;
   const long base = (long)blockIdx.x * 64;
   const int rows = (int)min((long)64, (long)B - base);
   tile_copy<true>(tile, stride, q + base * nq, rows, nq);
   __syncthreads();
   const bool valid = lane < rows;
-  double* row = tile + lane * stride;
-  double* hlds = tile + 64 * stride + lane;   // packed Hessian, element e at hlds[e * 64]
+  real* row = tile + lane * stride;
+  real* hlds = tile + 64 * stride + lane;   // packed Hessian, element e at hlds[e * 64]
   if (!valid) {
     for (int i = 0; i < nq; ++i) row[i] = tile[i];
   }
@@ -1521,7 +1549,7 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
   const double* tg = targets + pb * target_stride + D->target_off;
   Q4 Qt = Q4{tg[0], tg[1], tg[2], tg[3]};
   V3 pt = v3(tg[4], tg[5], tg[6]);
-  double qc[NC], x[NC];
+  real qc[NC], x[NC];
   load_chain_q<NC>(D, row, qc);
 #pragma unroll
   for (int k = 0; k < NC; ++k) x[k] = 0.0;
@@ -1567,7 +1595,7 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
         iters = it + 1;
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
-          double vk = x[k] * inv_dt;
+          real vk = x[k] * inv_dt;
           x[k] = vk;
           qc[k] = qc[k] + dt * vk;
         }
@@ -1580,14 +1608,15 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
   if (vrow) {
 #pragma unroll
     for (int k = 0; k < NC; ++k)
-      if (D->seg_dof[k] >= 0) vrow[D->seg_dof[k]] = x[k];
+      if (D->seg_dof[k] >= 0) vrow[D->seg_dof[k]] = (double)x[k];
   }
   if (valid) {
     status_out[pb] = status;
     if (iters_out) iters_out[pb] = (HANDOFF && handed) ? (iters | MK_ITER_CONT_BIT) : iters;
     if (err_out) {
       double* eo = err_out + pb * 6;
-      eo[0] = e.v.x; eo[1] = e.v.y; eo[2] = e.v.z; eo[3] = e.w.x; eo[4] = e.w.y; eo[5] = e.w.z;
+      eo[0] = (double)e.v.x; eo[1] = (double)e.v.y; eo[2] = (double)e.v.z;
+      eo[3] = (double)e.w.x; eo[4] = (double)e.w.y; eo[5] = (double)e.w.z;
     }
   }
   __syncthreads();
@@ -1597,21 +1626,22 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
 // Per-lane copy of n doubles with the loads of eight elements in flight together (a plain
 // loop waits for every element's round trip in turn; nothing else hides that latency at one
 // wave per SIMD).
-MK_DEV void lane_copy(double* __restrict__ dst, const double* __restrict__ src, int n) {
+template <typename TD, typename TS>
+MK_DEV void lane_copy(TD* __restrict__ dst, const TS* __restrict__ src, int n) {
   int i = 0;
   for (; i + 8 <= n; i += 8) {
-    double t[8];
+    TS t[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) t[k] = src[i + k];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) dst[i + k] = t[k];
+    for (int k = 0; k < 8; ++k) dst[i + k] = (TD)t[k];
   }
-  double t[8];
+  TS t[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) t[k] = (i + k < n) ? src[i + k] : 0.0;
+  for (int k = 0; k < 8; ++k) t[k] = (i + k < n) ? src[i + k] : TS(0.0);
 #pragma unroll
   for (int k = 0; k < 8; ++k)
-    if (i + k < n) dst[i + k] = t[k];
+    if (i + k < n) dst[i + k] = (TD)t[k];
 }
 
 // The callers' loop for batches much larger than the machine, with early exit: a persistent
@@ -1631,25 +1661,25 @@ template <int NC, bool HANDOFF = false>
 __global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __restrict__ D_arg,
                                                            double* __restrict__ q,
                                                            const double* __restrict__ targets, int target_stride,
-                                                           double dt, double damping, int B, int chunk, int refill_min,
-                                                           int max_iters, double pos_tol, double ori_tol,
+                                                           real dt, real damping, int B, int chunk, int refill_min,
+                                                           int max_iters, real pos_tol, real ori_tol,
                                                            double* __restrict__ v_out, int32_t* __restrict__ iters_out,
                                                            double* __restrict__ err_out,
                                                            int32_t* __restrict__ status_out, int handoff_live = 0) {
   const MkFusedDesc* D = D_arg;
-  extern __shared__ double tile[];
+  extern __shared__ real tile[];
   const int nq = D->nq, nv = D->nv;
   const int stride = nq | 1;
-  const double inv_dt = 1.0 / dt;
+  const real inv_dt = 1.0 / dt;
   const int lane = threadIdx.x;
-  double* row = tile + lane * stride;
-  double* hlds = tile + 64 * stride + lane;
+  real* row = tile + lane * stride;
+  real* hlds = tile + 64 * stride + lane;
   long next = (long)blockIdx.x * chunk;                       // wave-uniform: first problem not yet handed out
   const long last = min((long)B, next + (long)chunk);
   const bool sync_rows = D->any_posture_lm != 0;
   long pid = -1;                                              // -1: nothing yet, -2: chunk exhausted
   bool live = false, input_bad = false, handed = false;
-  double qc[NC], x[NC];
+  real qc[NC], x[NC];
 #pragma unroll
   for (int k = 0; k < NC; ++k) { qc[k] = 0.0; x[k] = 0.0; }
   Q4 Qt = Q4{1, 0, 0, 0};
@@ -1671,13 +1701,14 @@ __global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __
           double* vr = v_out + pid * nv;
 #pragma unroll
           for (int k = 0; k < NC; ++k)
-            if (D->seg_dof[k] >= 0) vr[D->seg_dof[k]] = x[k];
+            if (D->seg_dof[k] >= 0) vr[D->seg_dof[k]] = (double)x[k];
         }
         status_out[pid] = status;
         if (iters_out) iters_out[pid] = (HANDOFF && handed) ? (iters | MK_ITER_CONT_BIT) : iters;
         if (err_out) {
           double* eo = err_out + pid * 6;
-          eo[0] = e.v.x; eo[1] = e.v.y; eo[2] = e.v.z; eo[3] = e.w.x; eo[4] = e.w.y; eo[5] = e.w.z;
+          eo[0] = (double)e.v.x; eo[1] = (double)e.v.y; eo[2] = (double)e.v.z;
+          eo[3] = (double)e.w.x; eo[4] = (double)e.w.y; eo[5] = (double)e.w.z;
         }
       }
       const long mine = next + __popcll(wm & ((1ull << lane) - 1ull));
@@ -1726,7 +1757,7 @@ __global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __
         ++it;
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
-          const double vk = x[k] * inv_dt;
+          const real vk = x[k] * inv_dt;
           x[k] = vk;
           qc[k] = qc[k] + dt * vk;
         }
@@ -1758,28 +1789,28 @@ __global__ MK_KERNEL_ATTR void fused_iterate_stream_kernel(const MkFusedDesc* __
 // steps_out and solves_out must be given.
 template <int NC, bool HANDOFF = false>
 __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restrict__ D_arg, double* __restrict__ q,
-                                                    const double* __restrict__ goals, double dt, double damping,
+                                                    const double* __restrict__ goals, real dt, real damping,
                                                     int B, int chunk, int refill_min, int max_steps, int max_iters,
-                                                    double pos_tol, double ori_tol, double wp_pos_thr,
-                                                    double wp_pos_step, double wp_rot_thr,
+                                                    real pos_tol, real ori_tol, real wp_pos_thr,
+                                                    real wp_pos_step, real wp_rot_thr,
                                                     int32_t* __restrict__ steps_out,
                                                     int32_t* __restrict__ reached_out,
                                                     int32_t* __restrict__ solves_out,
                                                     int32_t* __restrict__ status_out, int handoff_live = 0) {
   const MkFusedDesc* D = D_arg;
-  extern __shared__ double tile[];
+  extern __shared__ real tile[];
   const int nq = D->nq;
   const int stride = nq | 1;
-  const double inv_dt = 1.0 / dt;
+  const real inv_dt = 1.0 / dt;
   const int lane = threadIdx.x;
-  double* row = tile + lane * stride;
-  double* hlds = tile + 64 * stride + lane;
+  real* row = tile + lane * stride;
+  real* hlds = tile + 64 * stride + lane;
   long next = (long)blockIdx.x * chunk;
   const long last = min((long)B, next + (long)chunk);
   const bool sync_rows = D->any_posture_lm != 0;
   long pid = -1;                                   // -1: nothing yet, -2: chunk exhausted
   bool live = false, input_bad = false, now = false, reached = false, in_step = false, handed = false;
-  double qc[NC], x[NC];
+  real qc[NC], x[NC];
 #pragma unroll
   for (int k = 0; k < NC; ++k) { qc[k] = 0.0; x[k] = 0.0; }
   Q4 Qg = Q4{1, 0, 0, 0}, Qt = Q4{1, 0, 0, 0};
@@ -1897,7 +1928,7 @@ static hipError_t launch_step(const MkFusedDesc* d_desc, int nq, const double* q
                               int target_stride, double dt, double damping, int B, double* v, int32_t* status,
                               hipStream_t stream) {
   const int blocks = (B + 63) / 64;
-  const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
+  const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(real);
   if (hipError_t e = allow_lds<fused_step_kernel<NC>>(lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(fused_step_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, q, targets, target_stride,
                      dt, damping, B, v, status);
@@ -1910,13 +1941,15 @@ static hipError_t launch_iterate(const MkFusedDesc* d_desc, int nq, double* q, c
                                  double ori_tol, double* v, int32_t* iters, double* err, int32_t* status,
                                  hipStream_t stream, int handoff_live) {
   const int blocks = (B + 63) / 64;
-  const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
+  const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(real);
+#if !defined(MK_F32)   // (the cooperative kernels that take a hand-off are float64 only)
   if (handoff_live > 0) {
     if (hipError_t e = allow_lds<fused_iterate_kernel<NC, true>>(lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((fused_iterate_kernel<NC, true>), dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
                        target_stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status, handoff_live);
     return hipGetLastError();
   }
+#endif
   if (hipError_t e = allow_lds<fused_iterate_kernel<NC, false>>(lds); e != hipSuccess) return e;
   hipLaunchKernelGGL((fused_iterate_kernel<NC, false>), dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
                      target_stride, dt, damping, B, max_iters, pos_tol, ori_tol, v, iters, err, status, 0);
@@ -1945,7 +1978,8 @@ static hipError_t launch_iterate_stream(const MkFusedDesc* d_desc, int nq, doubl
                                         int32_t* status, hipStream_t stream, int handoff_live) {
   const int chunk = (B + blocks - 1) / blocks;
   const int refill_min = (int)mk_opt(MK_OPT_STREAM_REFILL);   // tuning
-  const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
+  const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(real);
+#if !defined(MK_F32)
   if (handoff_live > 0) {
     if (hipError_t e = allow_lds<fused_iterate_stream_kernel<NC, true>>(lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((fused_iterate_stream_kernel<NC, true>), dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
@@ -1953,6 +1987,7 @@ static hipError_t launch_iterate_stream(const MkFusedDesc* d_desc, int nq, doubl
                        status, handoff_live);
     return hipGetLastError();
   }
+#endif
   if (hipError_t e = allow_lds<fused_iterate_stream_kernel<NC, false>>(lds); e != hipSuccess) return e;
   hipLaunchKernelGGL((fused_iterate_stream_kernel<NC, false>), dim3(blocks), dim3(64), lds, stream, d_desc, q, targets,
                      target_stride, dt, damping, B, chunk, refill_min, max_iters, pos_tol, ori_tol, v, iters, err,
@@ -1972,6 +2007,7 @@ hipError_t mk_fused_launch_step(int nc, const MkFusedDesc* d_desc, int nq, const
   }
 }
 
+#if !defined(MK_F32)
 template <int NC>
 static hipError_t launch_step_ext(const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nq, const double* q,
                                   const double* targets, int target_stride, double dt, double damping, int B, double* v,
@@ -1979,7 +2015,7 @@ static hipError_t launch_step_ext(const MkFusedDesc* d_desc, const MkFusedExt* d
                                   int it, int max_iters, double pos_tol, double ori_tol) {
   const int blocks = (B + 63) / 64;
   // per lane: its q, and H or (before it) the scratch of the collision screen
-  const size_t lds = (size_t)64 * ((nq | 1) + std::max(NC * (NC + 1) / 2, screen_doubles)) * sizeof(double);
+  const size_t lds = (size_t)64 * ((nq | 1) + std::max(NC * (NC + 1) / 2, screen_doubles)) * sizeof(real);
   if (hipError_t e = allow_lds<fused_step_ext_kernel<NC>>(lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(fused_step_ext_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, d_ext, q, targets,
                      target_stride, dt, damping, B, v, status, iters, err, it, max_iters, pos_tol, ori_tol);
@@ -2006,7 +2042,7 @@ static hipError_t launch_rows(const MkFusedDesc* d_desc, const MkFusedExt* d_ext
                               const double* targets, int target_stride, double dt, double damping, int B, double* v,
                               int32_t* status, hipStream_t stream) {
   // per wave: H and the general rows of 64 problems, and the queue of pending indices
-  const size_t lds = (size_t)64 * (NC * (NC + 1) / 2 + MK_LANE_ROWS * nv) * sizeof(double) + 128 * sizeof(int32_t);
+  const size_t lds = (size_t)64 * (NC * (NC + 1) / 2 + MK_LANE_ROWS * nv) * sizeof(real) + 128 * sizeof(int32_t);
   // a model too wide for one wave's rows to fit the LDS of a compute unit skips this stage: its
   // pending problems all go to the general kernel
   if (lds > (size_t)160 * 1024) return hipSuccess;
@@ -2030,6 +2066,8 @@ hipError_t mk_fused_launch_rows(int nc, const MkFusedDesc* d_desc, const MkFused
   }
 }
 
+#endif  // !MK_F32
+
 // handoff_live > 0 (and an exit test, and `iters` given): the block-per-64 kernel may leave up to
 // that many problems per wave marked MK_ITER_CONT_BIT for mk_coop_launch_resume; *handed tells
 // whether this launch was of that kind.
@@ -2038,6 +2076,7 @@ hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, do
                                    double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
                                    int32_t* status, hipStream_t stream, int handoff_live, bool* handed) {
   if (!(handoff_live > 0 && iters != nullptr && pos_tol >= 0.0 && ori_tol >= 0.0 && max_iters > 2)) handoff_live = 0;
+  if (MK_IS_F32) handoff_live = 0;
   if (handed) *handed = handoff_live > 0;
   // With an exit test and more problems than twice the lanes of the machine, lanes stream
   // through the problems of a chunk (one persistent wave per slot); otherwise one block of 64
@@ -2085,7 +2124,8 @@ static hipError_t launch_move_to(const MkFusedDesc* d_desc, int nq, double* q, c
   const int blocks = std::max(1, std::min((B + 63) / 64, slots));
   const int chunk = (B + blocks - 1) / blocks;
   const int refill_min = (int)mk_opt(MK_OPT_STREAM_REFILL);   // tuning
-  const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(double);
+  const size_t lds = (size_t)64 * ((nq | 1) + NC * (NC + 1) / 2) * sizeof(real);
+#if !defined(MK_F32)
   if (handoff_live > 0) {
     if (hipError_t e = allow_lds<fused_move_to_kernel<NC, true>>(lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((fused_move_to_kernel<NC, true>), dim3(blocks), dim3(64), lds, stream, d_desc, q, goals, dt,
@@ -2093,6 +2133,7 @@ static hipError_t launch_move_to(const MkFusedDesc* d_desc, int nq, double* q, c
                        wp_rot_thr, steps, reached, solves, status, handoff_live);
     return hipGetLastError();
   }
+#endif
   if (hipError_t e = allow_lds<fused_move_to_kernel<NC, false>>(lds); e != hipSuccess) return e;
   hipLaunchKernelGGL((fused_move_to_kernel<NC, false>), dim3(blocks), dim3(64), lds, stream, d_desc, q, goals, dt,
                      damping, B, chunk, refill_min, max_steps, max_iters, pos_tol, ori_tol, wp_pos_thr, wp_pos_step,
@@ -2107,6 +2148,7 @@ hipError_t mk_fused_launch_move_to(int nc, const MkFusedDesc* d_desc, int nq, do
                                    hipStream_t stream, int handoff_live, bool* handed) {
   // (the marks of the hand-off live in `steps`, and the resumed rollout continues its counters)
   if (!(handoff_live > 0 && steps != nullptr && solves != nullptr && max_iters > 0)) handoff_live = 0;
+  if (MK_IS_F32) handoff_live = 0;
   if (handed) *handed = handoff_live > 0;
   switch (nc) {
 #define MK_CASE(N)                                                                                              \

@@ -14,6 +14,7 @@ enum MkOption {
   MK_OPT_COOP,             // -1: the cooperative (16 lanes per problem) kernels by batch size; 0: never; 1: always
   MK_OPT_COOP_MAX_BATCH,   // largest batch the cooperative kernels take when MK_OPT_COOP is -1
   MK_OPT_HANDOFF,          // loops with an exit test on the block-per-64 kernel: -1 a wave hands its last 4 live problems to the cooperative kernel; 0 never; n > 0: its last n
+  MK_OPT_F32,              // 1: the step, loop and rollout entries run the fused kernels in float32 arithmetic (problems without such kernels are refused)
   MK_OPT_COUNT
 };
 

@@ -1,0 +1,166 @@
+"""The fused kernels in float32 arithmetic (option "f32": mk_fused32.hip, the source of
+mk_fused.hip with the scalar type switched) against the float64 C restatement of
+mink.solve_ik (mink/solve_ik.py:68-105) and of the callers' loop
+(interactive_scripts/teleop_mouse.py:105-121).
+
+Stated bound of the mode, for problems with a Levenberg-Marquardt term on the frame task
+(lm_damping = 1, what every caller of the reference sets: teleop_mouse.py:61-69,
+envs/mj_env.py:140-147) at any damping:
+
+    one step:  |v_f32 - v_f64|_inf <= 1e-3 * max(1, |v_f64|_inf)  rad/s
+    the loop:  the frame-task error reached differs by <= 2e-5 (norm), q by <= 2e-3
+
+measured 1.6e-4 rad/s, 6e-6 and 3e-4 on the sets below and in the sweep of tools/soak_f32.py; the
+float64 mode's bound is 1e-6 rad/s.  Without that term the error grows with the condition number
+of the Hessian (about 1e-7 cond); a factorisation that loses a pivot to rounding reports status 3
+with zero velocity instead of an answer."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from mink_amd import _lib as L
+from mink_amd import workloads as W
+from mink_amd.mjcf import load_builtin
+
+pytestmark = pytest.mark.gpu
+V_BOUND = 1e-3
+
+
+def dev(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+
+
+@pytest.fixture(scope="module")
+def env():
+    from mink_amd.engine import DeviceModel
+    model = load_builtin("tidybot_cube")
+    return model, DeviceModel(model, "cuda:0")
+
+
+def oracle(model, with_damping_task):
+    from oracle import c_oracle as co
+    postures = [dict(cost=W.posture_cost(model), target_q=W.home_q(model))]
+    if with_damping_task:
+        postures.append(dict(cost=W.base_damping_cost(model), target_q=model.qpos0.copy(), gain=0.0))
+    return co.COracle(model, postures=postures, velocity=W.VELOCITY_LIMITS)
+
+
+@pytest.mark.parametrize("damping", [1e-3, 1e-12])
+@pytest.mark.parametrize("with_damping_task", [False, True])
+@pytest.mark.parametrize("targets", ["near", "far"])
+def test_single_step_within_the_stated_bound_of_the_float64_oracle(env, damping, with_damping_task, targets):
+    from mink_amd.engine import DeviceProblem
+    model, dm = env
+    rng = np.random.default_rng(7)
+    B = 8192
+    q = W.sample_q(model, rng, B)
+    site = model.site_id("pinch_site")
+    if targets == "near":
+        tg = W.offset_targets(dm.frame_pose(dev(q), 2, site).cpu().numpy(), rng)
+    else:
+        tg = dm.frame_pose(dev(W.sample_q(model, rng, B)), 2, site).cpu().numpy()
+    prob = DeviceProblem(dm, W.task_specs(model, with_damping_task), W.limit_specs(model, True))
+    with L.options(f32=1):
+        v, st = prob.solve(dev(q), dev(tg), W.DT, damping)
+    v_ref, st_ref = oracle(model, with_damping_task).solve_ik(q, tg, W.DT, damping, nthreads=8)
+    assert not st_ref.any() and int(st.abs().sum()) == 0
+    d = np.abs(v.cpu().numpy() - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
+    print(f"float32 vs float64 oracle, {targets} targets, damping {damping:g}: max |dv| = {d.max():.3e}")
+    assert d.max() <= V_BOUND
+    # and it is float32 arithmetic that ran: the float64 kernels are within 1e-9 of the oracle
+    assert d.max() > 1e-8
+
+
+def test_loop_reaches_the_same_error_as_the_float64_oracle(env):
+    from mink_amd.engine import DeviceProblem
+    model, dm = env
+    rng = np.random.default_rng(8)
+    B = 4096
+    q0 = W.sample_q(model, rng, B)
+    site = model.site_id("pinch_site")
+    near = W.offset_targets(dm.frame_pose(dev(q0), 2, site).cpu().numpy(), rng)
+    far = dm.frame_pose(dev(W.sample_q(model, rng, B)), 2, site).cpu().numpy()
+    tg = np.where((np.arange(B) % 2 == 0)[:, None], far, near)
+    prob = DeviceProblem(dm, W.task_specs(model, False), W.limit_specs(model, True))
+    q = dev(q0)
+    with L.options(f32=1):
+        r = prob.iterate_(q, dev(tg), W.DT, W.DAMPING, 20, 1e-4, 1e-4)
+    q_ref, it_ref, err_ref, st_ref = oracle(model, False).iterate(q0, tg, W.DT, W.DAMPING, 20, 1e-4, 1e-4, nthreads=8)
+    assert not st_ref.any() and int(r["status"].abs().sum()) == 0
+    it = r["iters"].cpu().numpy()
+    # a problem whose error passes the exit threshold within rounding of it may leave one pass
+    # earlier or later; the others take the same number of solves
+    differ = it != it_ref
+    assert differ.mean() < 0.01 and np.abs(it - it_ref).max() <= 1
+    same = ~differ
+    en, en_ref = np.linalg.norm(r["err"].cpu().numpy(), axis=1), np.linalg.norm(err_ref, axis=1)
+    dq = np.abs(q.cpu().numpy() - q_ref)[same].max()
+    print(f"float32 loop vs float64 oracle: max |d err norm| = {np.abs(en - en_ref)[same].max():.3e}, max |dq| = {dq:.3e}, "
+          f"solve counts differ on {int(differ.sum())} of {B}")
+    assert np.abs(en - en_ref)[same].max() <= 2e-5
+    assert dq <= 2e-3
+
+
+def test_rollouts_match_the_float64_kernels(env):
+    """mk_move_to_batch in float32: the waypoint rollouts reach their goals like the float64 ones."""
+    import mink_amd as mk
+    model, dm = env
+    rng = np.random.default_rng(9)
+    B = 1024
+    q0 = W.sample_q(model, rng, B)
+    ftask = mk.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0)
+    ptask = mk.PostureTask(model, cost=W.posture_cost(model))
+    ptask.set_target(W.home_q(model))
+    wcfg = mk.LinearWaypointReachConfig(0.01, 0.08, 0.05, 0.3)
+    out = {}
+    for f32 in (0, 1):
+        cfg = mk.Configuration(model, dev(q0), device="cuda:0")
+        start = cfg.get_transform_frame_to_world("pinch_site", "site")
+        g = torch.Generator(device="cpu").manual_seed(3)
+        goal_pos = start.translation() + (torch.rand((B, 3), generator=g, dtype=torch.float64) * 0.2 - 0.1).to("cuda:0")
+        goal_rot = start.rotation() @ mk.SO3.exp((torch.rand((B, 3), generator=g, dtype=torch.float64) * 0.6 - 0.3).to("cuda:0"))
+        with L.options(f32=f32, coop=0, handoff=0):
+            ro = mk.move_to(cfg, ftask, [ftask, ptask], goal_pos, goal_rot, wcfg, max_steps=40)
+        out[f32] = (ro, cfg.q_tensor.clone())
+    (r64, q64), (r32, q32) = out[0], out[1]
+    reached64, reached32 = r64["reached"].bool(), r32["reached"].bool()
+    assert float(reached64.double().mean()) > 0.9
+    assert float((reached64 != reached32).double().mean()) < 0.01
+    same = (r64["steps"] == r32["steps"]) & reached64 & reached32
+    assert float(same.double().mean()) > 0.9
+    assert float((q64 - q32)[same].abs().max()) <= 5e-3
+
+
+def test_problems_without_float32_kernels_are_refused(env):
+    from mink_amd.engine import DeviceProblem
+    model, dm = env
+    tasks, limits = W.config4_specs(model)
+    prob = DeviceProblem(dm, tasks, limits)
+    q, tg = W.config4_inputs(model, dm, 64, 1)
+    with L.options(f32=1):
+        with pytest.raises(L.MinkAmdError, match="float32 kernels exist only"):
+            prob.solve(q, tg, W.DT, W.DAMPING)
+
+
+def test_lost_pivot_is_reported_not_answered(env):
+    """No Levenberg-Marquardt term, no posture cost, damping far below float32 resolution: the
+    Hessian is singular to working precision.  Status 3 and zero velocity, never NaN."""
+    from mink_amd.engine import DeviceProblem
+    model, dm = env
+    rng = np.random.default_rng(10)
+    B = 2048
+    q = W.sample_q(model, rng, B)
+    site = model.site_id("pinch_site")
+    tg = W.offset_targets(dm.frame_pose(dev(q), 2, site).cpu().numpy(), rng)
+    tasks = [dict(type=L.TASK_FRAME, frame_type=L.FRAME_TYPES["site"], frame_id=site, cost=np.ones(6), gain=1.0,
+                  lm_damping=0.0)]
+    prob = DeviceProblem(dm, tasks, W.limit_specs(model, True))
+    assert prob.fused
+    with L.options(f32=1):
+        v, st = prob.solve(dev(q), dev(tg), W.DT, 1e-10)
+    st, v = st.cpu().numpy(), v.cpu().numpy()
+    assert np.isfinite(v).all()
+    # (1: the dual iteration ran into its limit on a problem that rounding made inconsistent)
+    assert set(np.unique(st).tolist()) <= {0, 1, 3} and (st == 3).mean() > 0.5
+    assert not v[st == 3].any()

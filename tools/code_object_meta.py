@@ -46,6 +46,8 @@ def kernels_of(obj):
             res.append(rec)
     for rec, dm in zip(res, demangle([r["name"] for r in res])):
         rec["demangled"] = re.sub(r"\(anonymous namespace\)::", "", dm).split("(")[0].replace("void ", "")
+        if re.search(r"\breal\b", dm):      # the float32 build of the fused kernels takes `real` scalars
+            rec["demangled"] += " [float32]"
     return res
 
 
