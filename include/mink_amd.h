@@ -207,6 +207,22 @@ int mk_move_to_batch(const mk_problem* problem, double* d_q, const double* d_goa
                      int32_t* d_steps, int32_t* d_reached, int32_t* d_solves, int32_t* d_status,
                      void* stream);
 
+/* The same rollout for a problem outside the fused path that has a frame task (collision
+ * limits, relative frame tasks, several tasks, any tree): every outer step is issued as the passes
+ * of mk_solve_ik_iterate_batch's general form, so all max_steps x (max_iters + 1) passes are
+ * launched and the call lasts accordingly; nothing is allocated and nothing synchronises.
+ * `task_index` names the driven task (an MK_TASK_FRAME of the problem).  d_targets [B,
+ * target_stride] holds the targets of the other tasks and is working memory for the driven one
+ * (its slot is overwritten with the commanded pose of each step).  d_steps, d_reached, d_solves,
+ * d_status [B] as above but required; d_v [B, nv], d_iters [B], d_err [B, 6] hold the state of the
+ * loop and end as after the last step's mk_solve_ik_iterate_batch.
+ * Replaces the loop of envs/mj_env.py:212-230 around envs/mj_env.py:266-276 for such problems. */
+int mk_move_to_passes_batch(const mk_problem* problem, int32_t task_index, double* d_q, const double* d_goals,
+                            double* d_targets, const mk_waypoint_config* wp, double dt, double damping, int32_t B,
+                            int32_t max_steps, int32_t max_iters, double pos_tol, double ori_tol, int32_t* d_steps,
+                            int32_t* d_reached, int32_t* d_solves, int32_t* d_status, double* d_v, int32_t* d_iters,
+                            double* d_err, void* stream);
+
 /* Configuration.integrate_inplace minus the FK refresh (mink/configuration.py:228-236,
  * i.e. mujoco.mj_integratePos): d_q [B, nq] <- d_q (+) dt * d_v [B, nv]. */
 int mk_integrate_batch(const mk_model* model, double* d_q, const double* d_v, double dt,

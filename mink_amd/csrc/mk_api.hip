@@ -1215,7 +1215,7 @@ static long handoff_threshold(const mk_problem* p) {
 // than silently computed in float64.
 static bool want_f32() { return mk_opt(MK_OPT_F32) != 0; }
 static int f32_refusal(const mk_problem* p) {
-  if (p->fused && !p->staged) return MK_OK;
+  if (p && p->fused && !p->staged) return MK_OK;
   return fail(MK_ERR_UNSUPPORTED, "option f32 is set, but float32 kernels exist only for problems of the fused path "
                                   "without collision limits or relative frame tasks");
 }
@@ -1294,6 +1294,54 @@ int mk_solve_ik_batch(const mk_problem* p, const double* d_q, const double* d_ta
   return MK_OK;
 }
 
+// The callers' loop (interactive_scripts/teleop_mouse.py:105-121) outside the one-launch path, as
+// passes of kernels; no device memory is allocated: the optional outputs of the iterated entry
+// hold the state of the loop.  `iters` carries a done bit (MK_ITER_DONE_BIT) while the loop runs
+// -- a problem that enters with it set is left alone by every launch --, `err` the latest
+// frame-task error, `v` the velocity of each problem's last solve, `status` accumulates.  Nothing
+// synchronises, so all max_iters passes are issued.
+static int iterate_passes(const mk_problem* p, double* d_q, const double* d_targets, double dt, double damping, int32_t B,
+                          int32_t max_iters, double pos_tol, double ori_tol, double* d_v, int32_t* d_iters, double* d_err,
+                          int32_t* d_status, hipStream_t st) {
+  if (p->staged && mk_opt(MK_OPT_STAGED_LOOP) != 0) {
+    // Staged problems: one pass = the structured kernel in its loop mode (error, exit test and
+    // bookkeeping of the pass, then the solve of the problems still in the loop), the rows stage
+    // and the general kernel for what is pending, and the integration.
+    for (int it = 0; it <= max_iters; ++it) {
+      MK_HIP(mk_fused_launch_step_ext(p->nc_kernel, p->d_fused, p->d_ext, p->info.nq, d_q, d_targets, p->info.target_stride,
+                                      dt, damping, B, d_v, d_status, st, 3 * p->h_ext.ncgeom + 4 * p->h_ext.norient, d_iters,
+                                      d_err, it, max_iters, pos_tol, ori_tol));
+      if (it == max_iters) break;
+      if (p->h_ext.ncpair > 0) {
+        MK_HIP(mk_fused_launch_rows(p->nc_kernel, p->d_fused, p->d_ext, p->info.nv, d_q, d_targets, p->info.target_stride, dt,
+                                    damping, B, d_v, d_status, st));
+        MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets,
+                               p->info.target_stride, dt, damping, B, nullptr, nullptr, nullptr, nullptr, d_v, d_status, -1,
+                               nullptr, nullptr, st, nullptr, true, true));
+      }
+      MK_HIP(mk_generic_integrate(p->model->dev, d_q, d_v, dt, B, st, d_iters));
+    }
+    return MK_OK;
+  }
+  // General path: the wave-per-problem kernels; the exit test reads the first frame task's error.
+  int frame_k = -1;
+  for (int t = 0; t < p->h_dense.ntask && frame_k < 0; ++t)
+    if (p->h_dense.task[t].type == MK_TASK_FRAME) frame_k = t;
+  for (int it = 0; it <= max_iters; ++it) {
+    if (frame_k >= 0)
+      MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets,
+                             p->info.target_stride, 1.0, 0.0, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             frame_k, d_err, nullptr, st, d_iters, false));
+    MK_HIP(mk_generic_iterate_mark(d_iters, d_err, B, it, max_iters, pos_tol, ori_tol, frame_k >= 0, st));
+    if (it == max_iters) break;
+    MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets,
+                           p->info.target_stride, dt, damping, B, nullptr, nullptr, nullptr, nullptr, d_v, d_status, -1,
+                           nullptr, nullptr, st, d_iters, true));
+    MK_HIP(mk_generic_integrate(p->model->dev, d_q, d_v, dt, B, st, d_iters));
+  }
+  return MK_OK;
+}
+
 int mk_solve_ik_iterate_batch(const mk_problem* p, double* d_q, const double* d_targets, double dt, double damping,
                               int32_t B, int32_t max_iters, double pos_tol, double ori_tol, double* d_v,
                               int32_t* d_iters, double* d_err, int32_t* d_status, void* stream) {
@@ -1310,67 +1358,18 @@ int mk_solve_ik_iterate_batch(const mk_problem* p, double* d_q, const double* d_
                                      static_cast<hipStream_t>(stream), 0, nullptr));
     return MK_OK;
   }
-  if (p->staged && mk_opt(MK_OPT_STAGED_LOOP) != 0) {
-    // Staged problems: one pass of the loop = the structured kernel in its loop mode (error, exit
-    // test and bookkeeping of the pass, then the solve of the problems still in the loop), the
-    // rows stage and the general kernel for what is pending, and the integration.  The optional
-    // outputs hold the state of the loop, as on the general path below.
+  if ((p->staged && mk_opt(MK_OPT_STAGED_LOOP) != 0) || !p->fused) {
+    if (!p->staged && !p->dense) return fail(MK_ERR_UNSUPPORTED, "dense path unavailable: %s", p->dense_why.c_str());
     if (!d_v || !d_iters || !d_err)
       return fail(MK_ERR_INVALID, "outside the fused path d_v, d_iters and d_err hold the state of the loop and must be given");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int nv = p->info.nv;
     MK_HIP(hipMemsetAsync(d_iters, 0, sizeof(int32_t) * (size_t)B, st));
     MK_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * (size_t)B, st));
-    MK_HIP(hipMemsetAsync(d_v, 0, sizeof(double) * (size_t)B * nv, st));
+    MK_HIP(hipMemsetAsync(d_v, 0, sizeof(double) * (size_t)B * p->info.nv, st));
     MK_HIP(hipMemsetAsync(d_err, 0, sizeof(double) * (size_t)B * 6, st));
-    for (int it = 0; it <= max_iters; ++it) {
-      MK_HIP(mk_fused_launch_step_ext(p->nc_kernel, p->d_fused, p->d_ext, p->info.nq, d_q, d_targets, p->info.target_stride,
-                                      dt, damping, B, d_v, d_status, st, 3 * p->h_ext.ncgeom + 4 * p->h_ext.norient, d_iters,
-                                      d_err, it, max_iters, pos_tol, ori_tol));
-      if (it == max_iters) break;
-      if (p->h_ext.ncpair > 0) {
-        MK_HIP(mk_fused_launch_rows(p->nc_kernel, p->d_fused, p->d_ext, p->info.nv, d_q, d_targets, p->info.target_stride, dt,
-                                    damping, B, d_v, d_status, st));
-        MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets,
-                               p->info.target_stride, dt, damping, B, nullptr, nullptr, nullptr, nullptr, d_v, d_status, -1,
-                               nullptr, nullptr, st, nullptr, true, true));
-      }
-      MK_HIP(mk_generic_integrate(p->model->dev, d_q, d_v, dt, B, st, d_iters));
-    }
-    MK_HIP(mk_generic_iterate_finish(d_iters, B, st));
-    return MK_OK;
-  }
-  if (!p->fused) {
-    // General path: the same loop as a sequence of launches of the wave-per-problem kernels.
-    // The optional outputs double as the loop's state (no device memory is allocated):
-    // `iters` carries a done bit while the loop runs, `err` the latest frame-task error,
-    // `v` the velocity of each problem's last solve.  Problems that have left the loop are
-    // skipped by every later launch; nothing synchronises, so all max_iters passes are
-    // issued.
-    if (!p->dense) return fail(MK_ERR_UNSUPPORTED, "dense path unavailable: %s", p->dense_why.c_str());
-    if (!d_v || !d_iters || !d_err)
-      return fail(MK_ERR_INVALID, "outside the fused path d_v, d_iters and d_err hold the state of the loop and must be given");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    int frame_k = -1;
-    for (int t = 0; t < p->h_dense.ntask && frame_k < 0; ++t)
-      if (p->h_dense.task[t].type == MK_TASK_FRAME) frame_k = t;
-    const int nv = p->info.nv;
-    MK_HIP(hipMemsetAsync(d_iters, 0, sizeof(int32_t) * (size_t)B, st));
-    MK_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * (size_t)B, st));
-    MK_HIP(hipMemsetAsync(d_v, 0, sizeof(double) * (size_t)B * nv, st));
-    MK_HIP(hipMemsetAsync(d_err, 0, sizeof(double) * (size_t)B * 6, st));
-    for (int it = 0; it <= max_iters; ++it) {
-      if (frame_k >= 0)
-        MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets,
-                               p->info.target_stride, 1.0, 0.0, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                               frame_k, d_err, nullptr, st, d_iters, false));
-      MK_HIP(mk_generic_iterate_mark(d_iters, d_err, B, it, max_iters, pos_tol, ori_tol, frame_k >= 0, st));
-      if (it == max_iters) break;
-      MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets,
-                             p->info.target_stride, dt, damping, B, nullptr, nullptr, nullptr, nullptr, d_v, d_status, -1,
-                             nullptr, nullptr, st, d_iters, true));
-      MK_HIP(mk_generic_integrate(p->model->dev, d_q, d_v, dt, B, st, d_iters));
-    }
+    if (int rc = iterate_passes(p, d_q, d_targets, dt, damping, B, max_iters, pos_tol, ori_tol, d_v, d_iters, d_err, d_status, st);
+        rc != MK_OK)
+      return rc;
     MK_HIP(mk_generic_iterate_finish(d_iters, B, st));
     return MK_OK;
   }
@@ -1430,6 +1429,51 @@ int mk_move_to_batch(const mk_problem* p, double* d_q, const double* d_goals, co
     MK_HIP(mk_coop_launch_move_to_resume(p->nc_kernel, p->d_fused, d_q, d_goals, dt, damping, B, max_steps, max_iters,
                                          pos_tol, ori_tol, wp->pos_threshold, wp->pos_step_size, wp->rot_threshold,
                                          d_steps, d_reached, d_solves, d_status, 2048, static_cast<hipStream_t>(stream)));
+  return MK_OK;
+}
+
+int mk_move_to_passes_batch(const mk_problem* p, int32_t task_index, double* d_q, const double* d_goals, double* d_targets,
+                            const mk_waypoint_config* wp, double dt, double damping, int32_t B, int32_t max_steps,
+                            int32_t max_iters, double pos_tol, double ori_tol, int32_t* d_steps, int32_t* d_reached,
+                            int32_t* d_solves, int32_t* d_status, double* d_v, int32_t* d_iters, double* d_err,
+                            void* stream) {
+  if (!p || !wp) return fail(MK_ERR_INVALID, "null problem or waypoint configuration");
+  if (B < 0 || max_steps < 0 || max_iters < 0 || !(dt > 0.0) || !(damping >= 0.0))
+    return fail(MK_ERR_INVALID, "B, max_steps, max_iters, dt or damping out of range");
+  if (!(wp->pos_threshold >= 0.0) || !(wp->pos_step_size > 0.0) || !(wp->rot_threshold >= 0.0))
+    return fail(MK_ERR_INVALID, "waypoint thresholds / step size out of range");
+  if (B == 0) return MK_OK;
+  MK_ON_DEVICE(p->model);
+  if (!d_q || !d_goals || !d_targets || !d_steps || !d_reached || !d_solves || !d_status || !d_v || !d_iters || !d_err)
+    return fail(MK_ERR_INVALID, "null argument");
+  if (want_f32()) return f32_refusal(nullptr);
+  if (!p->dense) return fail(MK_ERR_UNSUPPORTED, "dense path unavailable: %s", p->dense_why.c_str());
+  if (task_index < 0 || task_index >= p->h_dense.ntask || p->h_dense.task[task_index].type != MK_TASK_FRAME)
+    return fail(MK_ERR_INVALID, "task_index must name a frame task of the problem");
+  // (the exit test of the IK loop reads the first frame task's error: the reference's loop tests
+  // the driven task, envs/mj_env.py:270-275)
+  for (int t = 0; t < task_index; ++t)
+    if (p->h_dense.task[t].type == MK_TASK_FRAME)
+      return fail(MK_ERR_UNSUPPORTED, "the driven frame task must be the first frame task of the problem");
+  const MkDenseTask& T = p->h_dense.task[task_index];
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MK_HIP(hipMemsetAsync(d_steps, 0, sizeof(int32_t) * (size_t)B, st));
+  MK_HIP(hipMemsetAsync(d_reached, 0, sizeof(int32_t) * (size_t)B, st));
+  MK_HIP(hipMemsetAsync(d_solves, 0, sizeof(int32_t) * (size_t)B, st));
+  MK_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * (size_t)B, st));
+  MK_HIP(hipMemsetAsync(d_iters, 0, sizeof(int32_t) * (size_t)B, st));
+  MK_HIP(hipMemsetAsync(d_v, 0, sizeof(double) * (size_t)B * p->info.nv, st));
+  MK_HIP(hipMemsetAsync(d_err, 0, sizeof(double) * (size_t)B * 6, st));
+  for (int step = 0; step < max_steps; ++step) {
+    MK_HIP(mk_generic_move_to_begin(p->model->dev, d_q, B, T.body, T.lpos, T.lquat, d_goals, wp->pos_threshold,
+                                    wp->pos_step_size, wp->rot_threshold, d_targets, p->info.target_stride, T.target_off,
+                                    d_iters, d_steps, d_reached, d_solves, step == 0, st));
+    if (int rc = iterate_passes(p, d_q, d_targets, dt, damping, B, max_iters, pos_tol, ori_tol, d_v, d_iters, d_err, d_status,
+                                st);
+        rc != MK_OK)
+      return rc;
+  }
+  MK_HIP(mk_generic_move_to_end(d_iters, d_solves, B, st));
   return MK_OK;
 }
 

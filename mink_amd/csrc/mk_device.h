@@ -154,6 +154,8 @@ struct MkFusedExt {
 // the shared source convert to it instead of promoting the arithmetic to float64.  Arrays in
 // global memory (q, targets, v) stay float64 in both builds.
 #if defined(MK_F32)
+// (a namespace of its own: V3, Q4 ... have another layout than in the float64 translation units)
+namespace mk_f32 {
 struct real {
   float v;
   real() = default;
@@ -587,3 +589,8 @@ MK_DEV bool waypoint_step(Q4 Qc, V3 tc, Q4 Qg, V3 pg, real pos_thr, real pos_ste
   const V3 eul = quat_rpy(qmul(Qg, qconj(Qc)));
   return pos_reached && sqrt(dot(eul, eul)) < rot_thr;
 }
+
+#if defined(MK_F32)
+}  // namespace mk_f32
+using namespace mk_f32;
+#endif

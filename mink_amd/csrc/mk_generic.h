@@ -125,6 +125,13 @@ hipError_t mk_generic_iterate_mark(int32_t* iters, const double* err, int B, int
 hipError_t mk_generic_resolve_pending(int32_t* status, int B, hipStream_t s);
 // Clears the done bits: `iters` then holds the solves executed.
 hipError_t mk_generic_iterate_finish(int32_t* iters, int B, hipStream_t s);
+// Start of one outer step of a waypoint rollout run as passes (mk_move_to_passes_batch) and the
+// bookkeeping after the last one; see the kernels.
+hipError_t mk_generic_move_to_begin(const MkDevModel& m, const double* q, int B, int body, const double* lpos,
+                                    const double* lquat, const double* goals, double pos_thr, double pos_step,
+                                    double rot_thr, double* targets, int target_stride, int target_off, int32_t* iters,
+                                    int32_t* steps, int32_t* reached, int32_t* solves, bool first, hipStream_t s);
+hipError_t mk_generic_move_to_end(int32_t* iters, int32_t* solves, int B, hipStream_t s);
 // Pose (d_pose != null) and/or body-frame Jacobian (d_jac != null) of a frame given
 // by its body and local offset.
 hipError_t mk_generic_frame(const MkDevModel& m, const double* q, int B, int body, const double* lpos,

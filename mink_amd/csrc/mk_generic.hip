@@ -130,7 +130,67 @@ __global__ void resolve_pending_kernel(int32_t* __restrict__ status, int B) {
   if (b < B && (status[b] & MK_STATUS_PENDING) != 0) status[b] = 1;
 }
 
+// One outer step of the waypoint rollout begins (envs/mj_env.py:212-230): the solves of the step
+// before are added to the problem's count; a problem whose generator has reported its goal reached
+// is out of the rollout (done bit: every launch of the step leaves it alone); any other gets its
+// next commanded pose (LinearWaypointReach.step, envs/robot_utils.py:131-160) written into the driven
+// frame task's slot of its target row, one more step on its counter and, when the generator says so,
+// the reached flag -- this step's IK still runs for it, like the reference's `break` after `step`.
+__global__ void move_to_begin_kernel(MkDevModel m, const double* __restrict__ q, int B, int body, V3 lpos, Q4 lquat,
+                                     const double* __restrict__ goals, double pos_thr, double pos_step, double rot_thr,
+                                     double* __restrict__ targets, int target_stride, int target_off,
+                                     int32_t* __restrict__ iters, int32_t* __restrict__ steps,
+                                     int32_t* __restrict__ reached, int32_t* __restrict__ solves, int first) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (!first) solves[b] += iters[b] & ~MK_ITER_DONE_BIT;
+  if (reached[b]) {
+    iters[b] = MK_ITER_DONE_BIT;
+    return;
+  }
+  const double* qb = q + b * m.nq;
+  const int adr = m.path_adr[body], len = m.path_len[body];
+  BodyState st = body_state_identity();
+  NoEmit none;
+  for (int i = 0; i < len; ++i) advance_body<false>(m, qb, m.path_data[adr + i], st, none);
+  const V3 tc = st.p + mul(st.R, lpos);
+  const Q4 Qc = qmul(st.Q, lquat);
+  const double* g = goals + b * 7;
+  Q4 Qt;
+  V3 pt;
+  const bool now = waypoint_step(Qc, tc, Q4{g[0], g[1], g[2], g[3]}, v3(g[4], g[5], g[6]), pos_thr, pos_step, rot_thr, Qt, pt);
+  double* t = targets + b * target_stride + target_off;
+  t[0] = Qt.w; t[1] = Qt.x; t[2] = Qt.y; t[3] = Qt.z; t[4] = pt.x; t[5] = pt.y; t[6] = pt.z;
+  steps[b] += 1;
+  if (now) reached[b] = 1;
+  iters[b] = 0;
+}
+
+// After the last outer step: its solves join the count, and `iters` is left without state bits.
+__global__ void move_to_end_kernel(int32_t* __restrict__ iters, int32_t* __restrict__ solves, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int32_t n = iters[b] & ~MK_ITER_DONE_BIT;
+  solves[b] += n;
+  iters[b] = n;
+}
+
 }  // namespace
+
+hipError_t mk_generic_move_to_begin(const MkDevModel& m, const double* q, int B, int body, const double* lpos,
+                                    const double* lquat, const double* goals, double pos_thr, double pos_step,
+                                    double rot_thr, double* targets, int target_stride, int target_off, int32_t* iters,
+                                    int32_t* steps, int32_t* reached, int32_t* solves, bool first, hipStream_t s) {
+  hipLaunchKernelGGL(move_to_begin_kernel, dim3((B + 63) / 64), dim3(64), 0, s, m, q, B, body,
+                     V3{lpos[0], lpos[1], lpos[2]}, Q4{lquat[0], lquat[1], lquat[2], lquat[3]}, goals, pos_thr, pos_step,
+                     rot_thr, targets, target_stride, target_off, iters, steps, reached, solves, first ? 1 : 0);
+  return hipGetLastError();
+}
+
+hipError_t mk_generic_move_to_end(int32_t* iters, int32_t* solves, int B, hipStream_t s) {
+  hipLaunchKernelGGL(move_to_end_kernel, dim3((B + 255) / 256), dim3(256), 0, s, iters, solves, B);
+  return hipGetLastError();
+}
 
 hipError_t mk_generic_resolve_pending(int32_t* status, int B, hipStream_t s) {
   hipLaunchKernelGGL(resolve_pending_kernel, dim3((B + 255) / 256), dim3(256), 0, s, status, B);

@@ -273,6 +273,31 @@ class DeviceProblem:
         return out
 
 
+    def move_to_passes_(self, task_index: int, q: torch.Tensor, goals: torch.Tensor, targets: torch.Tensor, wp, dt: float,
+                        damping: float, max_steps: int, max_iters: int, pos_tol: float, ori_tol: float) -> dict:
+        """Waypoint reaching for a problem outside the fused path (``mk_move_to_passes_batch``): every
+        outer step as passes of the general loop.  ``targets`` [B, target_stride] carries the other
+        tasks' targets; the slot of the driven frame task (``task_index``) is working memory.
+        Returns dict(steps, reached, solves, status, iters, err, v)."""
+        B = q.shape[0]
+        _check_tensor(q, (B, self.nq), torch.float64, "q")
+        _check_tensor(goals, (B, 7), torch.float64, "goals")
+        _check_tensor(targets, (B, self.target_stride), torch.float64, "targets")
+        out = {k: torch.empty((B,), dtype=torch.int32, device=self.device)
+               for k in ("steps", "reached", "solves", "status", "iters")}
+        out["err"] = torch.empty((B, 6), dtype=torch.float64, device=self.device)
+        out["v"] = torch.empty((B, self.nv), dtype=torch.float64, device=self.device)
+        cfg = L.WaypointConfig(float(wp.pos_threshold), float(wp.pos_step_size), float(wp.rot_threshold),
+                               float(wp.rot_step_size))
+        with torch.cuda.device(self.device):
+            L.check(self.lib.mk_move_to_passes_batch(
+                self.handle, int(task_index), q.data_ptr(), goals.data_ptr(), targets.data_ptr(), C.byref(cfg), float(dt),
+                float(damping), B, int(max_steps), int(max_iters), float(pos_tol), float(ori_tol), out["steps"].data_ptr(),
+                out["reached"].data_ptr(), out["solves"].data_ptr(), out["status"].data_ptr(), out["v"].data_ptr(),
+                out["iters"].data_ptr(), out["err"].data_ptr(), _stream_ptr(self.device)))
+        return out
+
+
 def qp_solve(P: torch.Tensor, c: torch.Tensor, G: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None):
     """Batched dense QP: min 1/2 x'Px + c'x s.t. Gx <= h. Returns (x [B, n], status [B])."""
     lib = L.load_library()

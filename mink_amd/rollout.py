@@ -82,7 +82,9 @@ def move_to(configuration, frame_task, tasks: Sequence, target_pos, target_rot: 
     if not any(t is frame_task for t in tasks):
         raise ValueError("frame_task must be one of tasks")
     # One launch for the whole rollout when the fused kernels serve the task / limit set and
-    # the driven task is their (single) frame task; otherwise the same loop step by step.
+    # the driven task is their (single) frame task; one library call queueing the passes of
+    # every step for other problems; the host loop below remains as the form both are checked
+    # against (and for a driven task that is not the problem's first frame task).
     from ._problems import get_problem
     from .solve_ik import _check_solver, _resolve_limits
     from .tasks import FrameTask
@@ -93,16 +95,28 @@ def move_to(configuration, frame_task, tasks: Sequence, target_pos, target_rot: 
         saved = frame_task.transform_target_to_world
         frame_task.transform_target_to_world = goal        # any valid pose: only its shape matters here
         try:
-            prob, _ = get_problem(configuration, tasks, _resolve_limits(configuration, limits))
+            prob, targets = get_problem(configuration, tasks, _resolve_limits(configuration, limits))
         finally:
             frame_task.transform_target_to_world = saved
+        goals = goal.wxyz_xyz.to(dtype=torch.float64)
+        if goals.ndim == 1:
+            goals = goals[None, :].expand(B, -1)
         if prob.fused and prob.target_stride == 7:
-            goals = goal.wxyz_xyz.to(dtype=torch.float64)
-            if goals.ndim == 1:
-                goals = goals[None, :].expand(B, -1)
             res = prob.move_to_(configuration.q_tensor, goals.contiguous(), cfg, dt, damping, max_steps, max_iters,
                                 pos_threshold, ori_threshold)
             configuration._report_status(res["status"])     # the reference's assert on a failed QP
+            return dict(steps=res["steps"], reached=res["reached"].bool(), solves=res["solves"].to(torch.int64))
+        # Any other problem whose first frame task is the driven one (collision limits, relative
+        # frame tasks, other trees): the whole rollout as launches of the general loop's kernels,
+        # queued by one library call -- no host round trip per step.
+        index = next(i for i, t in enumerate(tasks) if t is frame_task)
+        first_frame = next(i for i, t in enumerate(tasks) if type(t) is FrameTask)
+        if not prob.fused and index == first_frame:
+            if targets.shape[0] != B:
+                targets = targets.expand(B, -1)
+            res = prob.move_to_passes_(index, configuration.q_tensor, goals.contiguous(), targets.contiguous().clone(), cfg,
+                                       dt, damping, max_steps, max_iters, pos_threshold, ori_threshold)
+            configuration._report_status(res["status"])
             return dict(steps=res["steps"], reached=res["reached"].bool(), solves=res["solves"].to(torch.int64))
     return _move_to_stepwise(configuration, frame_task, tasks, target_pos, target_rot, cfg, dt, solver, damping,
                              max_steps, max_iters, pos_threshold, ori_threshold, limits)

@@ -157,12 +157,110 @@ def test_move_to_single_launch_matches_stepwise(kernel_form):
     r = a["reached"]
     assert 0 < int(r.sum()) < B and int(a["steps"].min()) < max_steps
     np.testing.assert_allclose(cfg_a.q.cpu().numpy(), cfg_b.q.cpu().numpy(), rtol=0, atol=1e-9)
-    # a task set outside the fused path takes the stepwise route
-    rel = mink.RelativeFrameTask("pinch_site", "site", "base_link", "body", 0.1, 0.1)
-    rel.set_target_from_configuration(mink.Configuration(model, q0[:4]))
-    cfg_c = mink.Configuration(model, q0[:4])
-    c = mink.move_to(cfg_c, frame, [frame, rel, posture], goal_pos[:4], SO3(goal_rot.wxyz[:4]), CFG, max_steps=3)
-    assert int(c["steps"].max()) <= 3 and int(c["solves"].sum()) > 0
+
+
+def _config4_rollout_inputs(B, seed):
+    """Benchmark config 4 as objects of the host mirror: Frame + RelativeFrame + Posture tasks,
+    Configuration + Velocity + CollisionAvoidance limits, the cube next to a gripper pad in a
+    quarter of the problems."""
+    import mink_amd as mink
+    from mink_amd import workloads as W
+    from mink_amd.engine import DeviceModel
+    model = mink.load_builtin("tidybot_cube")
+    dm = DeviceModel(model, "cuda:0")
+    q0, _ = W.config4_inputs(model, dm, B, seed)
+    q0 = q0.cpu().numpy()
+    frame = mink.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0)
+    rel = mink.RelativeFrameTask("pinch_site", "site", "base_link", "body", 0.3, 0.3)
+    rel.set_target_from_configuration(mink.Configuration(model, q0))
+    posture = mink.PostureTask(model, cost=W.posture_cost(model))
+    posture.set_target(W.home_q(model))
+    limits = [mink.ConfigurationLimit(model), mink.VelocityLimit(model, W.VELOCITY_LIMITS),
+              mink.CollisionAvoidanceLimit(model, [(list(W.PADS), ["cube_geom", "floor"])])]
+    return model, q0, frame, rel, posture, limits
+
+
+@pytest.mark.gpu
+def test_move_to_passes_for_a_staged_problem_matches_stepwise():
+    """A problem outside the fused path (collision limits, a relative frame task): mink.move_to queues
+    the whole rollout through mk_move_to_passes_batch; same counts and configurations as the host
+    loop over outer steps, which issues the same kernels one step at a time."""
+    import mink_amd as mink
+    from mink_amd import rollout
+    from mink_amd._problems import get_problem
+    B, max_steps = 700, 7
+    model, q0, frame, rel, posture, limits = _config4_rollout_inputs(B, 21)
+    cfg_a, cfg_b = mink.Configuration(model, q0), mink.Configuration(model, q0)
+    rng = np.random.default_rng(22)
+    start = cfg_a.get_transform_frame_to_world("pinch_site", "site")
+    goal_pos = start.translation() + torch.tensor(rng.uniform(-0.2, 0.2, (B, 3)), device="cuda:0")
+    goal_rot = start.rotation() @ SO3.exp(torch.tensor(rng.uniform(-0.5, 0.5, (B, 3)), device="cuda:0"))
+    goal_pos[:20] = start.translation()[:20] + 0.003            # reached in the first step
+    goal_rot.wxyz[:20] = start.rotation().wxyz[:20]
+    frame.set_target(start)
+    prob, _ = get_problem(cfg_a, [frame, rel, posture], limits)
+    assert prob.staged and not prob.fused
+    with cfg_a.deferred_checks(), cfg_b.deferred_checks():
+        a = mink.move_to(cfg_a, frame, [frame, rel, posture], goal_pos, goal_rot, CFG, max_steps=max_steps, limits=limits)
+        b = rollout._move_to_stepwise(cfg_b, frame, [frame, rel, posture], goal_pos, goal_rot, CFG, 1.0 / 200.0, "quadprog",
+                                      1e-3, max_steps, 20, 1e-4, 1e-4, limits)
+    assert torch.equal(a["steps"], b["steps"]) and torch.equal(a["reached"], b["reached"])
+    assert torch.equal(a["solves"], b["solves"])
+    assert int(a["steps"][:20].max()) == 1 and bool(a["reached"][:20].all())
+    assert 20 < int(a["reached"].sum()) < B
+    # (the waypoint step runs on the device in one, in torch in the other: rounding-level differences)
+    np.testing.assert_allclose(cfg_a.q.cpu().numpy(), cfg_b.q.cpu().numpy(), rtol=0, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_move_to_passes_matches_sequential_reference_loop():
+    """The same entry against the reference's own loop (envs/mj_env.py:209-276: waypoint step, then up
+    to 20 x solve_ik + integrate with the exit test) driving the numpy oracle one problem at a time,
+    collision rows and relative frame task included."""
+    import mink_amd as mink
+    from mink_amd import workloads as W
+    from oracle import ik_oracle as o
+    B, max_steps = 8, 4
+    model, q0, frame, rel, posture, limits = _config4_rollout_inputs(B, 23)
+    cfg = mink.Configuration(model, q0)
+    rng = np.random.default_rng(24)
+    start = cfg.get_transform_frame_to_world("pinch_site", "site")
+    goal_pos = start.translation() + torch.tensor(rng.uniform(-0.1, 0.1, (B, 3)), device="cuda:0")
+    goal_rot = start.rotation() @ SO3.exp(torch.tensor(rng.uniform(-0.3, 0.3, (B, 3)), device="cuda:0"))
+    rel_targets = rel.transform_target_to_root.wxyz_xyz.cpu().numpy()
+    with cfg.deferred_checks():
+        out = mink.move_to(cfg, frame, [frame, rel, posture], goal_pos, goal_rot, CFG, max_steps=max_steps, limits=limits)
+    gp, gq = goal_pos.cpu().numpy(), goal_rot.wxyz.cpu().numpy()
+    olimits = [o.ConfigurationLimit(model), o.VelocityLimit(model, W.VELOCITY_LIMITS),
+               o.CollisionAvoidanceLimit(model, [(list(W.PADS), ["cube_geom", "floor"])])]
+    n_rows_seen = 0
+    for b in range(B):
+        ocfg = o.Configuration(model, q0[b])
+        goal_euler = Rotation.from_quat(gq[b][[1, 2, 3, 0]]).as_euler("xyz")
+        n_steps, n_solves, reached = 0, 0, False
+        for _ in range(max_steps):
+            T = ocfg.get_transform_frame_to_world("pinch_site", "site")
+            eul = Rotation.from_quat(T[[1, 2, 3, 0]]).as_euler("xyz")
+            pos_cmd, half, reached = ref_step(gp[b], goal_euler, T[4:], eul, CFG)
+            target = np.concatenate([half.as_quat()[[3, 0, 1, 2]], pos_cmd])
+            tasks = [o.FrameTask("pinch_site", "site", 1.0, 1.0, lm_damping=1.0, target=target),
+                     o.RelativeFrameTask("pinch_site", "site", "base_link", "body", 0.3, 0.3, target=rel_targets[b]),
+                     o.PostureTask(cost=W.posture_cost(model), target_q=W.home_q(model))]
+            for _ in range(20):
+                n_rows_seen += int(np.isfinite(olimits[2].inequalities(ocfg, 1 / 200)[1]).sum())
+                v = o.solve_ik(ocfg, tasks, 1 / 200, damping=1e-3, limits=olimits)
+                ocfg.integrate_inplace(v, 1 / 200)
+                n_solves += 1
+                err = tasks[0].error(ocfg)
+                if np.linalg.norm(err[:3]) <= 1e-4 and np.linalg.norm(err[3:]) <= 1e-4:
+                    break
+            n_steps += 1
+            if reached:
+                break
+        assert int(out["steps"][b]) == n_steps and bool(out["reached"][b]) == reached
+        assert int(out["solves"][b]) == n_solves
+        np.testing.assert_allclose(cfg.q[b].cpu().numpy(), ocfg.q, rtol=0, atol=1e-7)
+    assert n_rows_seen > 0          # collision rows took part
 
 
 @pytest.mark.gpu
