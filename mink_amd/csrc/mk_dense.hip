@@ -55,6 +55,16 @@ MK_GPU double wave_sum(double v) {
   v += dpp_f64<0x143, 0xc>(v, 0.0);   // row_bcast:31 into rows 2 and 3
   return readlane_f64(v, 63);
 }
+// Maximum over the wave (NaN entries are ignored by fmax).
+MK_GPU double wave_max(double v) {
+  v = fmax(v, dpp_f64<0x111, 0xf>(v, -INFINITY));
+  v = fmax(v, dpp_f64<0x112, 0xf>(v, -INFINITY));
+  v = fmax(v, dpp_f64<0x114, 0xf>(v, -INFINITY));
+  v = fmax(v, dpp_f64<0x118, 0xf>(v, -INFINITY));
+  v = fmax(v, dpp_f64<0x142, 0xa>(v, -INFINITY));
+  v = fmax(v, dpp_f64<0x143, 0xc>(v, -INFINITY));
+  return readlane_f64(v, 63);
+}
 MK_GPU double bcast(double v, int lane) { return __shfl(v, lane); }
 MK_GPU V3 bcast3(V3 v, int lane) { return v3(__shfl(v.x, lane), __shfl(v.y, lane), __shfl(v.z, lane)); }
 
@@ -80,6 +90,15 @@ MK_GPU KeyId dpp_keyid(KeyId v, KeyId fill) {
   v = OP(v, dpp_keyid<0x142, 0xa>(v, fill));       \
   v = OP(v, dpp_keyid<0x143, 0xc>(v, fill));
 MK_GPU void wave_argmin(double& key, int& id) {
+  // the extreme key first (one value per step); only a tie between lanes -- rare -- needs the scan
+  // over (key, id) pairs
+  const double best = -wave_max(-key);
+  const uint64_t who = __ballot(key == best);
+  if (__popcll(who) == 1) {
+    id = __builtin_amdgcn_readlane(id, __ffsll((unsigned long long)who) - 1);
+    key = best;
+    return;
+  }
   KeyId v{key, id};
   const KeyId fill{INFINITY, 0x7fffffff};
   MK_WAVE_SCAN(v, fill, min_of)
@@ -87,6 +106,13 @@ MK_GPU void wave_argmin(double& key, int& id) {
   id = __builtin_amdgcn_readlane(v.id, 63);
 }
 MK_GPU void wave_argmax(double& key, int& id) {
+  const double best = wave_max(key);
+  const uint64_t who = __ballot(key == best);
+  if (__popcll(who) == 1) {
+    id = __builtin_amdgcn_readlane(id, __ffsll((unsigned long long)who) - 1);
+    key = best;
+    return;
+  }
   KeyId v{key, id};
   const KeyId fill{-INFINITY, -1};
   MK_WAVE_SCAN(v, fill, max_of)
@@ -200,10 +226,10 @@ MK_GPU bool geom_distance(int lane, int t1, V3 c1, const M3& r1, V3 s1, int t2, 
 // "all lanes read element (j, k)" are both free of bank conflicts.
 struct WLds {
   double *q, *tg, *bpos, *bquat, *daxis, *danch;
-  double *P;     // Hessian rows -> its Cholesky factor -> H^-1
-  double *W;     // task-row exchange buffer while building, then L^-1
-  double *HiN;   // H^-1 n_a for the active constraints a
-  double *Minv;  // (N' H^-1 N)^-1 of the active constraints
+  double *P;     // Hessian rows (the solver leaves them as they are)
+  double *W;     // task-row exchange buffer while building, then the solver's J (J J' = P^-1)
+  double *HiN;   // (same space as W)
+  double *Minv;  // the solver's triangular factor R of the active constraints; Cholesky work space of wide problems
   double *Gg, *hg, *gn;   // general rows, their bounds and norms
   double *c, *rinv, *xs, *hin, *u, *rr, *rv;
   int32_t *dkind, *act;
@@ -263,53 +289,6 @@ MK_GPU WLds carve(double* base, int n, int mg, int nq, int ts, int nbody) {
 }
 
 // ------------------------------------------------------------------ QP ----
-// In-place Cholesky of P (rows in LDS); lane i works on row i.  Leaves 1 / L_jj in rinv.
-MK_GPU bool chol_rows(WLds& s, int n, int lane) {
-  const int np = s.npad;
-  for (int j = 0; j < n; ++j) {
-    double t = 0.0;
-    if (lane >= j && lane < n) {
-      const double* ri = s.P + lane * np;
-      const double* rj = s.P + j * np;
-      t = ri[j];
-#pragma unroll 4
-      for (int k = 0; k < j; ++k) t -= ri[k] * rj[k];
-    }
-    const double d = bcast(t, j);
-    if (!(d > 0.0)) return false;
-    const double r = 1.0 / sqrt(d);
-    if (lane >= j && lane < n) s.P[lane * np + j] = (lane == j) ? d * r : t * r;
-    if (lane == j) s.rinv[j] = r;
-    __syncthreads();
-  }
-  return true;
-}
-
-// P (holding the Cholesky factor L) <- H^-1 = L^-T L^-1, through W = L^-1 (lane j builds
-// column j of W by forward substitution; lane i then builds row i of W'W).
-MK_GPU void invert_from_chol(WLds& s, int n, int lane) {
-  const int np = s.npad;
-  if (lane < n) {
-    for (int i = 0; i < n; ++i) {
-      double t = (i == lane) ? 1.0 : 0.0;
-      const double* li = s.P + i * np;
-#pragma unroll 4
-      for (int k = 0; k < i; ++k) t -= li[k] * s.W[k * np + lane];
-      s.W[i * np + lane] = t * s.rinv[i];
-    }
-  }
-  __syncthreads();
-  if (lane < n) {
-    for (int j = 0; j < n; ++j) {
-      double acc = 0.0;
-#pragma unroll 4
-      for (int k = j; k < n; ++k) acc += s.W[k * np + lane] * s.W[k * np + j];
-      s.P[lane * np + j] = acc;
-    }
-  }
-  __syncthreads();
-}
-
 // Value of `v` on lane `src` (wave-uniform index), delivered through scalar registers:
 // no LDS round trip, and the result can feed vector instructions directly.
 MK_GPU double readlane_f64(double v, int src) {
@@ -318,16 +297,21 @@ MK_GPU double readlane_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-// Register-resident version of chol_rows + invert_from_chol for an n x n matrix M (rows in
-// LDS, stride np), n <= NP, inverted in place: lane i keeps row
-// i of M / L in registers, then column i of L^-1, then row i of H^-1, and reads other
-// lanes' entries with readlane.  Fully unrolled: about 3 x n^2/2 fused multiply-adds and
-// as many lane reads, no barriers and no LDS traffic until H^-1 is written out.
+// Cholesky factor of the n x n matrix whose rows sit in LDS at H (stride np; left as it is),
+// n <= NP, taken in the elimination order `order` (position -> variable), and J = L^-T written to
+// Jm: row `variable`, with the column of elimination position k stored at n - 1 - k (the variables
+// eliminated last own the first columns, see the block start of gi_solve).  Lane i keeps row i of
+// the permuted matrix / of L in registers, then column i of L^-1, which is a row of J, and reads
+// other lanes' entries with readlane.  Fully unrolled: about n^2 fused multiply-adds and as many
+// lane reads, no barriers and no LDS traffic until J is written out.  False when a pivot is not
+// positive.
 template <int NP>
-__device__ __attribute__((noinline)) bool invert_regs(double* M, int np, int n, int lane) {
+__device__ __attribute__((noinline)) bool factor_regs(const double* H, double* Jm, const int32_t* order, int np, int n,
+                                                      int lane) {
+  const int var = lane < n ? order[lane] : 0;
   double A[NP];
 #pragma unroll
-  for (int j = 0; j < NP; ++j) A[j] = (lane < n && j < n) ? M[lane * np + j] : 0.0;
+  for (int j = 0; j < NP; ++j) A[j] = (lane < n && j < n) ? H[var * np + order[j]] : 0.0;
   // (lane j keeps 1 / L_jj in place of L_jj: only the reciprocal is used afterwards)
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
@@ -338,7 +322,7 @@ __device__ __attribute__((noinline)) bool invert_regs(double* M, int np, int n, 
       for (int k = 0; k < j; ++k) t -= A[k] * A[k];
       const double d = readlane_f64(t, j);
       if (!(d > 0.0)) return false;
-      const double r = 1.0 / sqrt(d);
+      const double r = mk_rsqrt(d);
       // column j of the other rows
       double u = A[j];
 #pragma unroll
@@ -347,7 +331,7 @@ __device__ __attribute__((noinline)) bool invert_regs(double* M, int np, int n, 
     }
     MK_SCHED_FENCE();
   }
-  // column `lane` of W = L^-1 by forward substitution; L_ik comes from lane i
+  // column `lane` of L^-1 by forward substitution; L_ik comes from lane i
   double Wc[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
@@ -360,50 +344,119 @@ __device__ __attribute__((noinline)) bool invert_regs(double* M, int np, int n, 
     }
     MK_SCHED_FENCE();
   }
-  // row `lane` of H^-1 = W'W: (i, j) entry = sum_{k >= j} W_ki W_kj, W_kj from lane j
+  __syncthreads();          // every lane has read `order`, which shares its space with the caller's list
 #pragma unroll
-  for (int j = 0; j < NP; ++j) {
-    if (j < n) {
-      double acc = 0.0;
-#pragma unroll
-      for (int k = j; k < NP; ++k) acc += Wc[k] * readlane_f64(Wc[k], j);
-      if (lane < n) M[lane * np + j] = acc;
+  for (int i = 0; i < NP; ++i)
+    if (lane < n && i < n) Jm[var * np + (n - 1 - i)] = Wc[i];
+  __syncthreads();
+  return true;
+}
+
+// The same through LDS for any n <= 64: the factor of the permuted matrix is formed in `tmp`
+// (n x np doubles), lane j then builds its row of J by forward substitution.
+MK_GPU bool factor_lds(const double* H, double* Jm, const int32_t* order, double* tmp, double* rinv, int np, int n,
+                       int lane) {
+  const int var = lane < n ? order[lane] : 0;
+  if (lane < n)
+    for (int j = 0; j < n; ++j) tmp[lane * np + j] = H[var * np + order[j]];
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    double t = 0.0;
+    if (lane >= j && lane < n) {
+      const double* ri = tmp + lane * np;
+      const double* rj = tmp + j * np;
+      t = ri[j];
+#pragma unroll 4
+      for (int k = 0; k < j; ++k) t -= ri[k] * rj[k];
     }
-    MK_SCHED_FENCE();
+    const double d = bcast(t, j);
+    if (!(d > 0.0)) return false;
+    const double r = mk_rsqrt(d);
+    if (lane >= j && lane < n) tmp[lane * np + j] = (lane == j) ? d * r : t * r;
+    if (lane == j) rinv[j] = r;
+    __syncthreads();
+  }
+  if (lane < n) {
+    double* jr = Jm + var * np + (n - 1);      // position k at jr[-k]
+    for (int i = 0; i < n; ++i) {
+      double t = (i == lane) ? 1.0 : 0.0;
+      const double* li = tmp + i * np;
+#pragma unroll 4
+      for (int k = lane; k < i; ++k) t -= li[k] * jr[-k];
+      jr[-i] = t * rinv[i];
+    }
   }
   __syncthreads();
   return true;
 }
 
+// R y = t and R'y = t for the upper triangular na x na matrix R (rows in LDS, stride na1;
+// rdiag holds the reciprocals of its diagonal); entry a of the right-hand side and of the solution
+// on lane a.  na sequential steps, each one lane read and one multiply-add per lane.
+MK_GPU double tri_back(const double* R, const double* rdiag, int na1, int na, double t, int lane) {
+  for (int b = na - 1; b >= 0; --b) {
+    const double yb = readlane_f64(t, b) * rdiag[b];
+    if (lane == b) t = yb;
+    else if (lane < b) t -= R[lane * na1 + b] * yb;
+  }
+  return lane < na ? t : 0.0;
+}
+MK_GPU double tri_fwd_t(const double* R, const double* rdiag, int na1, int na, double t, int lane) {
+  for (int b = 0; b < na; ++b) {
+    const double yb = readlane_f64(t, b) * rdiag[b];
+    if (lane == b) t = yb;
+    else if (lane > b && lane < na) t -= R[b * na1 + lane] * yb;
+  }
+  return lane < na ? t : 0.0;
+}
+
 // min 1/2 x'Px + c'x  s.t.  lo_i <= x_i <= hi_i (lane i) and Gg x <= hg (mg general rows),
-// by the Goldfarb-Idnani dual method.  P, c, Gg, hg in LDS (P is overwritten).  Constraint
-// ids: i = upper bound of x_i, n + i = lower bound, 2n + r = general row r.  The inverse of
-// the active constraints' Gram matrix N'H^-1N is kept explicitly and updated by bordering
-// (a constraint joins) or by a rank-one downdate (a constraint leaves); both need only
-// quantities the step computes anyway.  Returns the status; lane i receives x_i.
+// by the Goldfarb-Idnani dual method in its factorised form (what quadprog, the reference's QP
+// backend, implements: mink/solve_ik.py:101).  P, c, Gg, hg in LDS; P is left as it is.
+// Constraint ids: i = upper bound of x_i, n + i = lower bound, 2n + r = general row r.
+//
+// With P = L L', the method keeps J with J J' = P^-1 (J = L^-T at the start) and the upper
+// triangular R with J'N = [R; 0] for the normals N of the active constraints, so that for a
+// normal n+ and d = J'n+
+//   the step direction in x is      -J2 d2        (J2 = columns na.. of J, d2 likewise),
+//   its curvature                   n+'J2 J2'n+ = |d2|^2,
+//   the multipliers' direction      R^-1 d1.
+// A constraint joins by one Householder reflection of the columns J2 (which takes d2 to a multiple
+// of e1; the new column of R is (d1; that multiple)); one leaves by deleting its column of R and
+// restoring the triangle with Givens rotations of neighbouring rows of R / columns of J.  No
+// inverse is formed: errors grow with cond(P), not with its square.
+// Lane i owns row i of J (LDS, conflict-free by rows and by columns), lane a entry a of the
+// vectors over the active set.  Returns the status; lane i receives x_i.
 MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, double& x_out) {
   const int np = s.npad, na1 = s.na1;
-  // row `lane` of H itself, kept for the refinement passes at the end (P becomes H^-1 below)
-  double hrow[MK_MAX_NV];
-  if (lane < n) {
-    for (int j = 0; j < n; ++j) hrow[j] = s.P[lane * np + j];
+  double* const J = s.W;
+  double* const R = s.Minv;
+  double* const rdiag = s.rinv;
+  // J for the elimination order in s.act (position -> variable)
+  auto factor = [&]() -> bool {
+    if (n <= 16) return factor_regs<16>(s.P, J, s.act, np, n, lane);
+    if (n <= 24) return factor_regs<24>(s.P, J, s.act, np, n, lane);
+    if (n <= 32) return factor_regs<32>(s.P, J, s.act, np, n, lane);
+    return factor_lds(s.P, J, s.act, s.Minv, s.rinv, np, n, lane);
+  };
+  if (lane < n) s.act[lane] = lane;
+  __syncthreads();
+  if (!factor()) return 3;
+  const double* jrow = J + (lane < n ? lane : 0) * np;   // the lane's row of J
+  // x0 = -P^-1 c = -J (J'c)
+  {
+    double t = 0.0;
+    if (lane < n) {
+#pragma unroll 4
+      for (int i = 0; i < n; ++i) t += J[i * np + lane] * s.c[i];
+    }
+    if (lane < n) s.rr[lane] = t;
+    __syncthreads();
   }
-  if (n <= 16) {
-    if (!invert_regs<16>(s.P, np, n, lane)) return 3;
-  } else if (n <= 24) {
-    if (!invert_regs<24>(s.P, np, n, lane)) return 3;
-  } else if (n <= 32) {
-    if (!invert_regs<32>(s.P, np, n, lane)) return 3;
-  } else {
-    if (!chol_rows(s, n, lane)) return 3;
-    invert_from_chol(s, n, lane);
-  }
-  const double* Hi = s.P;   // H^-1, row-major
   double x = 0.0;
   if (lane < n) {
-    const double* hr = Hi + lane * np;
 #pragma unroll 4
-    for (int j = 0; j < n; ++j) x -= hr[j] * s.c[j];
+    for (int l = 0; l < n; ++l) x -= jrow[l] * s.rr[l];
   }
   for (int r = lane; r < mg; r += 64) {
     double acc = 0.0;
@@ -412,79 +465,192 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
     s.gact[r] = 0;
   }
 #if defined(MK_DENSE_ABLATE) && MK_DENSE_ABLATE == 3
-  x_out = x;   // tuning build only: factorisation, inverse and the unconstrained minimiser
+  x_out = x;   // tuning build only: factorisation and the unconstrained minimiser
   return 0;
 #endif
   bool act_hi = false, act_lo = false;
   int na = 0;
   int status = 1;
+
+  // Constraint with normal d = J'n+ (in s.hin) joins as number na: jd = J2 d2 of the lane's row,
+  // dd2 = |d2|^2 > 0.
+  auto join = [&](int p, double up, double jd, double dd2) {
+    const double dna = s.hin[na];
+    const double nrm = dd2 * mk_rsqrt(dd2);
+    const double alpha = dna > 0.0 ? -nrm : nrm;
+    const double beta = mk_rcp(dd2 - alpha * dna);          // 2 / v'v for v = d2 - alpha e1 (dd2 + |dna| nrm > 0)
+    if (lane < n) {
+      double* __restrict__ jr = J + lane * np;
+      const double* __restrict__ dv = s.hin;
+      const double bw = beta * (jd - alpha * jr[na]);        // beta (J2 v) of this row
+      jr[na] -= bw * (dna - alpha);
+      // (loads of a group of eight before its stores: the row and d share the LDS, and a
+      // read-modify-write loop would otherwise wait for every element's round trip in turn)
+      int l = na + 1;
+      for (; l + 8 <= n; l += 8) {
+        double a[8], h[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a[k] = jr[l + k]; h[k] = dv[l + k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) jr[l + k] = a[k] - bw * h[k];
+      }
+      double a[8], h[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { a[k] = l + k < n ? jr[l + k] : 0.0; h[k] = l + k < n ? dv[l + k] : 0.0; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (l + k < n) jr[l + k] = a[k] - bw * h[k];
+    }
+    if (lane < na) R[lane * na1 + na] = s.hin[lane];
+    if (lane == 0) {
+      R[na * na1 + na] = alpha;
+      rdiag[na] = alpha > 0.0 ? mk_rcp(alpha) : -mk_rcp(-alpha);
+      s.act[na] = p;
+      s.u[na] = up;
+      if (p >= 2 * n) s.gact[p - 2 * n] = 1;
+    }
+    if (p < n && lane == p) act_hi = true;
+    if (p >= n && p < 2 * n && lane == p - n) act_lo = true;
+    ++na;
+    __syncthreads();
+  };
+  // Active constraint number kb leaves.
+  auto leave = [&](int kb) {
+    const int idk = s.act[kb];
+    if (idk < n) { if (lane == idk) act_hi = false; }
+    else if (idk < 2 * n) { if (lane == idk - n) act_lo = false; }
+    else if (lane == 0) s.gact[idk - 2 * n] = 0;
+    for (int a = kb; a < na - 1; ++a) {
+      __syncthreads();
+      // rotation of rows (a, a + 1) of R that clears the subdiagonal entry of column a + 1
+      const double f = R[a * na1 + a + 1], g = R[(a + 1) * na1 + a + 1];
+      const double ih = mk_rsqrt(f * f + g * g);
+      const double cs = f * ih, sn = g * ih;
+      if (lane > a && lane < na) {
+        const double ra = R[a * na1 + lane], rb = R[(a + 1) * na1 + lane];
+        R[a * na1 + lane] = cs * ra + sn * rb;
+        R[(a + 1) * na1 + lane] = cs * rb - sn * ra;
+      }
+      if (lane < n) {
+        double* jr = J + lane * np;
+        const double ja = jr[a], jb = jr[a + 1];
+        jr[a] = cs * ja + sn * jb;
+        jr[a + 1] = cs * jb - sn * ja;
+      }
+    }
+    __syncthreads();
+    // columns kb + 1 .. of R move one to the left (lane = row), and with them act / u
+    const int idn = (lane >= kb && lane < na - 1) ? s.act[lane + 1] : 0;
+    const double un = (lane >= kb && lane < na - 1) ? s.u[lane + 1] : 0.0;
+    if (lane < na) {
+      double* rr = R + lane * na1;
+      for (int b = kb; b < na - 1; ++b) rr[b] = rr[b + 1];
+    }
+    __syncthreads();
+    if (lane >= kb && lane < na - 1) {
+      s.act[lane] = idn;
+      s.u[lane] = un;
+      rdiag[lane] = 1.0 / R[lane * na1 + lane];
+    }
+    --na;
+    __syncthreads();
+  };
+  // d = J'n+ for constraint p to s.hin; returns the lane's entry
+  auto normal_to_d = [&](int p) -> double {
+    double d = 0.0;
+    if (p < 2 * n) {
+      const int j = p < n ? p : p - n;
+      if (lane < n) d = (p < n) ? J[j * np + lane] : -J[j * np + lane];
+    } else if (lane < n) {
+      const double* g = s.Gg + (p - 2 * n) * np;
+#pragma unroll 4
+      for (int i = 0; i < n; ++i) d += J[i * np + lane] * g[i];
+    }
+    __syncthreads();          // readers of the previous contents of hin are done
+    if (lane < n) s.hin[lane] = d;
+    __syncthreads();
+    return d;
+  };
+
   // ---- block start: all bounds violated at the unconstrained minimiser at once ----
-  // With A = those bounds, x = x0 - H^-1 N u, u = (N'H^-1N)^-1 (N'x0 - b) is the minimiser on
-  // the face A; if every u_a >= 0 this is an S-pair and the dual method may start from it
-  // (one small inversion instead of one step per bound).  Bounds whose multiplier comes out
-  // negative are taken out and the face is solved again; after three tries the method
-  // starts from the empty set as usual.  Bounds on distinct dofs are linearly independent.
+  // With A = those bounds, x = x0 - P^-1 N u, u = (N'P^-1N)^-1 (N'x0 - b) is the minimiser on the
+  // face A; if every u_a >= 0 this is an S-pair and the dual method may start from it.  The factors
+  // for A come without a single reflection: with the variables of A eliminated LAST, the rows of
+  // J = L^-T that belong to them are zero outside the columns of A, so J'N is triangular as it
+  // stands -- constraint a sits at elimination position n - 1 - a, whose column is stored as
+  // column a -- and R is read off those rows.  One more factorisation (in registers) instead of
+  // one reflection of J through the LDS per bound.  Bounds whose multiplier comes out negative are
+  // taken out and the face is solved again; after three tries the method starts from the empty
+  // set as usual (J is a valid factor whatever the order it was formed in).
   {
     uint64_t mh = __ballot(lane < n && x - hi > 1e-12);
     uint64_t ml = __ballot(lane < n && lo - x > 1e-12);
+    bool accepted = false;
+#if defined(MK_DENSE_ABLATE) && MK_DENSE_ABLATE == 5
+    mh = ml = 0ull;    // tuning build only: no block start
+#endif
     for (int attempt = 0; attempt < 3 && (mh | ml) != 0ull; ++attempt) {
       const uint64_t mm = mh | ml;
       const int cnt = __popcll(mm);
-      if (cnt > 24) break;
-      const bool mine = (mm >> lane) & 1ull;
-      const int slot = __popcll(mm & ((1ull << lane) - 1ull));
-      if (mine) s.act[slot] = ((mh >> lane) & 1ull) ? lane : n + lane;
+      const uint64_t below = (1ull << lane) - 1ull;
+      const bool mine = lane < n && ((mm >> lane) & 1ull);
+      const int a_mine = __popcll(mm & below);                 // number of my bound among the active ones
+      const int pos = mine ? n - 1 - a_mine : __popcll(~mm & below);
       __syncthreads();
-      // lane a < cnt: its constraint, the Gram matrix row and the violation
+      if (lane < n) s.act[pos] = lane;
+      __syncthreads();
+      if (!factor()) break;                                    // (cannot happen: the first one went through)
+      // R, the constraint list, and the violations
+      const double sg = ((mh >> lane) & 1ull) ? 1.0 : -1.0;
+      if (mine) {
+        for (int b = 0; b <= a_mine; ++b) R[b * na1 + a_mine] = sg * jrow[b];
+        const double dg = sg * jrow[a_mine];
+        rdiag[a_mine] = dg > 0.0 ? mk_rcp(dg) : -mk_rcp(-dg);
+        s.act[a_mine] = sg > 0.0 ? lane : n + lane;
+      }
+      __syncthreads();
       const int ida = lane < cnt ? s.act[lane] : 0;
       const int ja = ida < n ? ida : ida - n;
-      const double sa = ida < n ? 1.0 : -1.0;
       const double xj = __shfl(x, ja), hj = __shfl(hi, ja), lj = __shfl(lo, ja);
       const double viol = lane < cnt ? (ida < n ? xj - hj : lj - xj) : 0.0;
-      if (lane < cnt) {
-        double* mr = s.Minv + lane * na1;
-        for (int b2 = 0; b2 < cnt; ++b2) {
-          const int idb = s.act[b2];
-          const int jb = idb < n ? idb : idb - n;
-          mr[b2] = (idb < n ? sa : -sa) * Hi[ja * np + jb];
-        }
-      }
-      __syncthreads();
-      const bool ok = cnt <= 16 ? invert_regs<16>(s.Minv, na1, cnt, lane) : invert_regs<24>(s.Minv, na1, cnt, lane);
-      if (!ok) break;
-      double ua = 0.0;
-      {
-        const double* mr = s.Minv + (lane < cnt ? lane : 0) * na1;
-        for (int b2 = 0; b2 < cnt; ++b2) ua += mr[b2] * readlane_f64(viol, b2);
-        if (lane >= cnt) ua = 0.0;
-      }
+      const double ua = tri_back(R, rdiag, na1, cnt, tri_fwd_t(R, rdiag, na1, cnt, viol, lane), lane);
       const uint64_t negm = __ballot(lane < cnt && ua < 0.0);
       if (negm != 0ull) {
         // take the bounds with a negative multiplier out of the candidate set
-        const double us = __shfl(ua, slot);
+        const double us = __shfl(ua, a_mine);
         const uint64_t dropm = __ballot(mine && us < 0.0);
         mh &= ~dropm;
         ml &= ~dropm;
-        __syncthreads();
         continue;
       }
-      // accepted: x, H^-1 N, multipliers, flags
-      for (int a = 0; a < cnt; ++a) {
-        const int idb = s.act[a];
-        const int jb = idb < n ? idb : idb - n;
-        const double sb = idb < n ? 1.0 : -1.0;
-        const double hcol = lane < n ? sb * Hi[jb * np + lane] : 0.0;   // (H^-1 n_a)_lane
-        if (lane < n) s.HiN[a * np + lane] = hcol;
-        x -= hcol * readlane_f64(ua, a);
-      }
+      // accepted: x = x0 - J1 (R u), multipliers, flags
       if (lane < cnt) s.u[lane] = ua;
-      act_hi = (mh >> lane) & 1ull;
-      act_lo = (ml >> lane) & 1ull;
+      __syncthreads();
+      double ru = 0.0;
+      if (lane < cnt)
+        for (int b = lane; b < cnt; ++b) ru += R[lane * na1 + b] * s.u[b];
+      if (lane < cnt) s.rr[lane] = ru;
+      __syncthreads();
+      if (lane < n) {
+#pragma unroll 4
+        for (int a = 0; a < cnt; ++a) x -= jrow[a] * s.rr[a];
+      }
+      act_hi = mine && sg > 0.0;
+      act_lo = mine && sg < 0.0;
       na = cnt;
+      accepted = true;
       __syncthreads();
       break;
     }
+    if (!accepted) {
+      na = 0;
+      act_hi = act_lo = false;
+    }
   }
+#if defined(MK_DENSE_ABLATE) && MK_DENSE_ABLATE == 6
+  x_out = x;    // tuning build only: stop after the block start
+  return 0;
+#endif
 #if defined(MK_DENSE_COUNT_STEPS)
   int n_full = 0, n_partial = 0;   // tuning build only: step counts returned in place of the status
 #endif
@@ -509,70 +675,37 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
     }
     wave_argmax(worst, p);
     if (p < 0) { status = 0; break; }
-    // ---- its normal n+, bound, and H^-1 n+ ----
-    double npl = 0.0, hin = 0.0, hp;
+    // ---- its normal n+ (the lane's component) and bound ----
+    double npl = 0.0, hp;
     if (p < 2 * n) {
       const int j = p < n ? p : p - n;
-      const double sg = p < n ? 1.0 : -1.0;
-      if (lane == j) npl = sg;
-      if (lane < n) hin = sg * Hi[j * np + lane];
-      hp = bcast(p < n ? hi : -lo, j);
+      if (lane == j) npl = p < n ? 1.0 : -1.0;
+      hp = readlane_f64(p < n ? hi : -lo, j);
     } else {
-      const int r = p - 2 * n;
-      if (lane < n) {
-        npl = s.Gg[r * np + lane];
-        const double* hr = Hi + lane * np;
-#pragma unroll 4
-        for (int j = 0; j < n; ++j) hin += hr[j] * s.Gg[r * np + j];
-      }
-      hp = s.hg[r];
+      if (lane < n) npl = s.Gg[(p - 2 * n) * np + lane];
+      hp = s.hg[p - 2 * n];
     }
-    const double nHn = wave_sum(npl * hin);
-    if (lane < n) s.hin[lane] = hin;
-    __syncthreads();
     double up = 0.0;
     bool failed = false;
     for (;;) {
-      // r = (N'H^-1N)^-1 N'H^-1 n+   (lane a works on active constraint a; values of other
-      // lanes are fetched with lane reads, the indices being wave-uniform)
-      double rva = 0.0;
-      {
-        const int ida = lane < na ? s.act[lane] : 0;
-        const int jb = ida < n ? ida : (ida < 2 * n ? ida - n : 0);
-        const double hj = __shfl(hin, jb);
-        if (lane < na) {
-          if (ida < 2 * n) {
-            rva = (ida < n) ? hj : -hj;
-          } else {
-            const double* g = s.Gg + (ida - 2 * n) * np;
+      const double d = normal_to_d(p);
+      const double dd = wave_sum(lane < n ? d * d : 0.0);                 // n+'P^-1 n+
+      const double dd2 = wave_sum(lane >= na && lane < n ? d * d : 0.0);  // curvature along the step
+      double jd = 0.0;
+      if (lane < n) {
 #pragma unroll 4
-            for (int j = 0; j < n; ++j) rva += g[j] * s.hin[j];
-          }
-        }
+        for (int l = na; l < n; ++l) jd += jrow[l] * s.hin[l];
       }
-      double ra = 0.0;
-      {
-        const double* mr = s.Minv + (lane < na ? lane : 0) * na1;
-        for (int b2 = 0; b2 < na; ++b2) ra += mr[b2] * readlane_f64(rva, b2);
-        if (lane >= na) ra = 0.0;
-      }
-      // step direction in x
-      double z = 0.0;
-      {
-        double acc = hin;
-        const double* hc = s.HiN + (lane < n ? lane : 0);
-        for (int a = 0; a < na; ++a) acc -= hc[a * np] * readlane_f64(ra, a);
-        z = lane < n ? -acc : 0.0;
-      }
-      const double nz = -wave_sum(npl * z);
-      const bool dependent = nz <= 1e-13 * nHn;
+      const double z = -jd;                                                // step direction in x
+      const double ra = tri_back(R, rdiag, na1, na, lane < na ? d : 0.0, lane);
+      const bool dependent = dd2 <= 1e-13 * dd;
       // largest step that keeps the multipliers non-negative
       double t1 = INFINITY;
       int kb = 1 << 30;
       if (lane < na && ra > 0.0) { t1 = s.u[lane] / ra; kb = lane; }
       wave_argmin(t1, kb);
-      const double viol = wave_sum(npl * x) - hp;
-      const double t2 = dependent ? INFINITY : viol / nz;
+      const double viol = (p < 2 * n ? (p < n ? readlane_f64(x, p) : -readlane_f64(x, p - n)) : wave_sum(npl * x)) - hp;
+      const double t2 = dependent ? INFINITY : viol * mk_rcp(dd2);
       const double t = fmin(t1, t2);
       if (!(t < INFINITY)) { status = 2; failed = true; break; }
       if (!dependent) x += t * z;
@@ -580,32 +713,10 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
       up += t;
       if (!dependent && t2 <= t1) {
         // full step: p joins the active set
-        const double is = 1.0 / nz;
-        if (lane < n) s.HiN[na * np + lane] = hin;
-        {
-          double* mr = s.Minv + (lane < na ? lane : 0) * na1;
-          for (int b2 = 0; b2 < na; ++b2) {
-            const double rb = readlane_f64(ra, b2);
-            if (lane < na) mr[b2] += ra * rb * is;
-          }
-          if (lane < na) {
-            mr[na] = -ra * is;
-            s.Minv[na * na1 + lane] = -ra * is;
-          }
-        }
-        if (lane == 0) {
-          s.Minv[na * na1 + na] = is;
-          s.act[na] = p;
-          s.u[na] = up;
-          if (p >= 2 * n) s.gact[p - 2 * n] = 1;
-        }
-        if (p < n && lane == p) act_hi = true;
-        if (p >= n && p < 2 * n && lane == p - n) act_lo = true;
-        ++na;
+        join(p, up, jd, dd2);
 #if defined(MK_DENSE_COUNT_STEPS)
         ++n_full;
 #endif
-        __syncthreads();
         break;
       }
       // partial step: the blocking constraint kb leaves the active set
@@ -613,56 +724,35 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
       ++n_partial;
 #endif
       __syncthreads();
-      const int idk = s.act[kb];
-      if (idk < n) { if (lane == idk) act_hi = false; }
-      else if (idk < 2 * n) { if (lane == idk - n) act_lo = false; }
-      else if (lane == 0) s.gact[idk - 2 * n] = 0;
-      if (lane < na && lane != kb) {
-        double* mr = s.Minv + lane * na1;
-        const double f = mr[kb] / s.Minv[kb * na1 + kb];
-        const double* mk = s.Minv + kb * na1;
-        for (int b2 = 0; b2 < na; ++b2) mr[b2] -= f * mk[b2];
-      }
-      __syncthreads();
-      const int last = na - 1;
-      if (kb != last) {
-        // the last active constraint takes slot kb (their order is immaterial)
-        if (lane < na) s.Minv[kb * na1 + lane] = s.Minv[last * na1 + lane];
-        __syncthreads();
-        if (lane < na) s.Minv[lane * na1 + kb] = s.Minv[lane * na1 + last];
-        if (lane < n) s.HiN[kb * np + lane] = s.HiN[last * np + lane];
-        if (lane == 0) { s.act[kb] = s.act[last]; s.u[kb] = s.u[last]; }
-      }
-      --na;
-      __syncthreads();
+      leave(kb);
     }
     if (failed) break;
   }
   // ---- refinement on the final active set ----
-  // The dual method reaches the optimum from the unconstrained minimiser through explicit
-  // inverses (H^-1, and the Gram matrix of the active rows formed from it), so its error grows
-  // like cond(H)^2: 1e-4 relative at cond(H) ~ 1e6 (small damping, no Levenberg-Marquardt
-  // term).  With A the final active set, two
-  // passes of iterative refinement on its KKT system -- residuals from H, c and the rows
-  // themselves, corrections through the same inverses,
-  //   r = H x + c + N u,  s = N'x - b,  du = (N'H^-1N)^-1 (s - N'H^-1 r),  dx = -H^-1 (r + N du)
-  // -- bring x back to working accuracy; active bounds are then met exactly.  A pass is kept
-  // only if the residuals it was computed from are smaller than those of the pass before (with
-  // a Hessian singular to working precision the inverses are too poor to refine anything).
+  // With A the final active set, up to two passes of iterative refinement on its KKT system --
+  // residuals from P, c and the rows themselves, corrections through the factors,
+  //   r = P x + c + N u,  s = N'x - b,  g = J'r,  y = R^-T s,
+  //   du = R^-1 (y - g1),  dx = -J (y; g2)
+  // -- bring x to working accuracy; active bounds are then met exactly.  A pass is kept only if
+  // the residuals it was computed from are smaller than those of the pass before.
+#if defined(MK_DENSE_ABLATE) && MK_DENSE_ABLATE == 4
+  x_out = x;    // tuning build only: no refinement, no final check
+  return status;
+#endif
   if (status == 0) {
     double x_prev = x, m_prev = INFINITY, s_kept = 0.0;
-    double hmax = lane < n ? hrow[lane] : 0.0;   // largest diagonal entry of H: x units -> gradient units
-    {
-      int idm = lane;
-      wave_argmax(hmax, idm);
-    }
+    // largest diagonal entry of P: x units -> gradient units
+    const double hmax = wave_max(lane < n ? s.P[lane * np + lane] : 0.0);
     for (int pass = 0; pass < 3; ++pass) {
+      __syncthreads();
       if (lane < n) s.xs[lane] = x;
       __syncthreads();
       double r = 0.0;
       if (lane < n) {
         r = s.c[lane];
-        for (int j = 0; j < n; ++j) r += hrow[j] * s.xs[j];
+        const double* pr = s.P + lane * np;
+#pragma unroll 4
+        for (int j = 0; j < n; ++j) r += pr[j] * s.xs[j];
       }
       for (int a = 0; a < na; ++a) {
         const int id = s.act[a];
@@ -692,12 +782,8 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
       if (!(m == m)) m = INFINITY;
       double ms = fabs(sres);
       if (!(ms == ms)) ms = INFINITY;
-      {
-        int idm = lane;
-        wave_argmax(m, idm);
-        idm = lane;
-        wave_argmax(ms, idm);
-      }
+      m = wave_max(m);
+      ms = wave_max(ms);
       if (!(m < m_prev)) {   // wave-uniform
         x = x_prev;
         break;
@@ -706,67 +792,42 @@ MK_GPU int gi_solve(WLds& s, int n, int mg, int lane, double lo, double hi, doub
       m_prev = m;
       s_kept = ms;
       if (pass == 2) break;
+      // residuals at rounding level of the gradient's own scale: nothing to refine
+      if (m <= 1e-13 * wave_max(lane < n ? fabs(s.c[lane]) + hmax * fabs(x) : 0.0)) break;
       if (lane < n) s.hin[lane] = r;
       __syncthreads();
-      double w = 0.0;
+      double g = 0.0;
       if (lane < n) {
-        const double* hr = Hi + lane * np;
-        for (int j = 0; j < n; ++j) w += hr[j] * s.hin[j];
-        s.rr[lane] = w;
+#pragma unroll 4
+        for (int i = 0; i < n; ++i) g += J[i * np + lane] * s.hin[i];
       }
+      const double y = tri_fwd_t(R, rdiag, na1, na, sres, lane);
+      const double du = tri_back(R, rdiag, na1, na, lane < na ? y - g : 0.0, lane);
+      if (lane < n) s.rr[lane] = lane < na ? y : g;
       __syncthreads();
-      // its component of N'H^-1 r
-      double rhs = 0.0;
-      {
-        const double wj = __shfl(w, ja);
-        if (lane < na) {
-          if (ida < n) rhs = sres - wj;
-          else if (ida < 2 * n) rhs = sres + wj;
-          else {
-            const double* g = s.Gg + (ida - 2 * n) * np;
-            double sw = 0.0;
-            for (int j = 0; j < n; ++j) sw += g[j] * s.rr[j];
-            rhs = sres - sw;
-          }
-        }
-      }
-      double du = 0.0;
-      {
-        const double* mr = s.Minv + (lane < na ? lane : 0) * na1;
-        for (int b2 = 0; b2 < na; ++b2) du += mr[b2] * readlane_f64(rhs, b2);
-        if (lane >= na) du = 0.0;
-      }
       bool small;
       {
-        double acc = w;
-        const double* hc = s.HiN + (lane < n ? lane : 0);
-        for (int a = 0; a < na; ++a) acc += hc[a * np] * readlane_f64(du, a);
+        double acc = 0.0;
+        if (lane < n) {
+#pragma unroll 4
+          for (int l = 0; l < n; ++l) acc += jrow[l] * s.rr[l];
+        }
         // a correction far below the size of x itself: x was accurate already, nothing to check
-        double dm = lane < n ? fabs(acc) : 0.0, xm = lane < n ? fabs(x) : 0.0;
-        int idm = lane;
-        wave_argmax(dm, idm);
-        idm = lane;
-        wave_argmax(xm, idm);
+        const double dm = wave_max(lane < n ? fabs(acc) : 0.0), xm = wave_max(lane < n ? fabs(x) : 0.0);
         small = dm <= 1e-11 * xm;
         if (lane < n) x -= acc;
       }
       if (small) break;   // wave-uniform
       if (lane < na) s.u[lane] += du;
-      __syncthreads();
     }
     if (act_hi && fabs(x - hi) <= 1e-9 * fmax(1.0, fabs(hi))) x = hi;
     if (act_lo && fabs(lo - x) <= 1e-9 * fmax(1.0, fabs(lo))) x = lo;
     // The dual method only looks for violations among the rows it holds inactive; the active ones
-    // are met by construction -- up to what the explicit inverses lose.  An answer that misses its
-    // own active rows by more than 1e-7 of its size (cond(P) ~ 1e9 with many dense rows) is not
-    // handed out as solved.
-    // Likewise for stationarity: a residual of H x + c + N u above 1e-7 of the gradient's own scale.
+    // are met by construction -- up to what the factors lose.  An answer that misses its own
+    // active rows by more than 1e-7 of its size is not handed out as solved.
+    // Likewise for stationarity: a residual of P x + c + N u above 1e-7 of the gradient's own scale.
     {
-      double xm = lane < n ? fabs(x) : 0.0, cm = lane < n ? fabs(s.c[lane]) : 0.0;
-      int idm = lane;
-      wave_argmax(xm, idm);
-      idm = lane;
-      wave_argmax(cm, idm);
+      const double xm = wave_max(lane < n ? fabs(x) : 0.0), cm = wave_max(lane < n ? fabs(s.c[lane]) : 0.0);
       if (!(s_kept <= 1e-7 * fmax(1.0, xm))) status = 1;
       if (!(m_prev <= 1e-7 * fmax(cm + hmax * xm, 1e-300))) status = 1;
     }

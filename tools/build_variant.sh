@@ -16,8 +16,14 @@ for f in mk_generic mk_dense mk_lie mk_api; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c mink_amd/csrc/$f.hip -o build_ab/$f.o &
   fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-sched-strategy=max-ilp "${fflags[@]}" -c mink_amd/csrc/mk_fused.hip -o build_ab/fused_$name.o
+if [ ${#fflags[@]} -gt 0 ] || [ ! -f build/obj/mk_fused.hip.o ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-sched-strategy=max-ilp "${fflags[@]}" -c mink_amd/csrc/mk_fused.hip -o build_ab/fused_$name.o
+else
+  cp build/obj/mk_fused.hip.o build_ab/fused_$name.o
+fi
 wait
 dobj=build_ab/mk_dense.o; [ ${#dflags[@]} -gt 0 ] && dobj=build_ab/dense_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared build_ab/fused_$name.o build_ab/mk_generic.o $dobj build_ab/mk_lie.o build_ab/mk_api.o -o build_ab/libmink_$name.so
+# (the cooperative and float32 kernels come from the regular build: python -c 'import __graft_entry__ as g; g.build()')
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared build_ab/fused_$name.o build_ab/mk_generic.o $dobj build_ab/mk_lie.o build_ab/mk_api.o \
+  build/obj/mk_coop.hip.o build/obj/mk_fused32.hip.o -o build_ab/libmink_$name.so
 echo build_ab/libmink_$name.so

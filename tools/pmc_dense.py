@@ -3,10 +3,12 @@ for rocprofv3 --pmc passes."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
+from mink_amd import _lib as L
 from mink_amd import workloads as W
 from mink_amd.engine import DeviceModel, DeviceProblem
 from mink_amd.mjcf import load_builtin
 
+L.set_option("staged", 0)      # the wave-per-problem kernel for every problem
 model = load_builtin("tidybot_cube")
 dm = DeviceModel(model, "cuda:0")
 tasks, limits = W.config4_specs(model)
