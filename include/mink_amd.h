@@ -137,6 +137,10 @@ typedef struct mk_problem_info {
                             that may be within its detection distance, and the general kernel on what
                             that one leaves (one frame task, optionally a relative frame task on the
                             same frame, posture tasks, any limits) */
+  int32_t staged_rows;   /* staged problems: 1 when that lane-per-problem kernel takes part; 0 when the
+                            model is too wide for its rows to fit the LDS of a compute unit (about
+                            nv > 60 with a 12-dof chain): every problem with a pair in range then goes
+                            straight to the general kernel */
 } mk_problem_info;
 
 /* Replaces mujoco.MjModel.from_xml_path + mujoco.MjData construction

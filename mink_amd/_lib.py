@@ -67,7 +67,8 @@ class LimitDesc(C.Structure):
 
 class ProblemInfo(C.Structure):
     _fields_ = [("nq", C.c_int32), ("nv", C.c_int32), ("target_stride", C.c_int32),
-                ("n_rows", C.c_int32), ("fused", C.c_int32), ("n_chain", C.c_int32), ("staged", C.c_int32)]
+                ("n_rows", C.c_int32), ("fused", C.c_int32), ("n_chain", C.c_int32), ("staged", C.c_int32),
+                ("staged_rows", C.c_int32)]
 
 
 class WaypointConfig(C.Structure):

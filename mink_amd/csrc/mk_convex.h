@@ -315,8 +315,17 @@ MK_CVX void cvx_mpr(int lane, const CvxShape& A, const CvxShape& B, double& dept
   const V3 e0 = v2 - v1, e1 = v3_ - v1, e2 = p - v1;
   const double d00 = dot(e0, e0), d01 = dot(e0, e1), d11 = dot(e1, e1), d20 = dot(e2, e0), d21 = dot(e2, e1);
   const double den = d00 * d11 - d01 * d01;
-  const double lv = (d11 * d20 - d01 * d21) / den;
-  const double lw = (d00 * d21 - d01 * d20) / den;
+  // a portal that has collapsed to a segment or a point (three support points in line) has no
+  // barycentric coordinates: the foot of the origin on its longer edge instead (never NaN rows)
+  double lv = 0.0, lw = 0.0;
+  if (den > 1e-14 * d00 * d11) {
+    lv = (d11 * d20 - d01 * d21) / den;
+    lw = (d00 * d21 - d01 * d20) / den;
+  } else if (d00 >= d11 && d00 > 0.0) {
+    lv = fmin(fmax(d20 / d00, 0.0), 1.0);
+  } else if (d11 > 0.0) {
+    lw = fmin(fmax(d21 / d11, 0.0), 1.0);
+  }
   const double lu = 1.0 - lv - lw;
   const V3 pa = lu * a1 + lv * a2 + lw * a3, pb = lu * b1 + lv * b2 + lw * b3;
   pos = 0.5 * (pa + pb);

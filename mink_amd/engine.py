@@ -105,6 +105,7 @@ class DeviceProblem:
         self.fused = bool(info.fused)
         self.n_chain = info.n_chain
         self.staged = bool(info.staged)
+        self.staged_rows = bool(info.staged_rows)
         # posture targets the device copies currently hold, by task index
         self._posture_targets = {i: np.ascontiguousarray(s["target_q"], dtype=np.float64).tobytes()
                                  for i, s in enumerate(task_specs) if s["type"] == L.TASK_POSTURE}

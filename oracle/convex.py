@@ -251,8 +251,14 @@ def mpr(A, B):
     e0, e1, e2 = v2 - v1, v3 - v1, p - v1
     d00, d01, d11, d20, d21 = e0 @ e0, e0 @ e1, e1 @ e1, e2 @ e0, e2 @ e1
     den = d00 * d11 - d01 * d01
-    lv = (d11 * d20 - d01 * d21) / den
-    lw = (d00 * d21 - d01 * d20) / den
+    lv = lw = 0.0
+    if den > 1e-14 * d00 * d11:
+        lv = (d11 * d20 - d01 * d21) / den
+        lw = (d00 * d21 - d01 * d20) / den
+    elif d00 >= d11 and d00 > 0.0:          # collapsed portal: foot on its longer edge
+        lv = min(max(d20 / d00, 0.0), 1.0)
+    elif d11 > 0.0:
+        lw = min(max(d21 / d11, 0.0), 1.0)
     lam = [1.0 - lv - lw, lv, lw]
     pa = lam[0] * a1 + lam[1] * a2 + lam[2] * a3
     pb = lam[0] * b1 + lam[1] * b2 + lam[2] * b3

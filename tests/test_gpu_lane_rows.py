@@ -84,7 +84,7 @@ def inputs(model, dm, n, seed, near=HAND):
 def solve_general(dm, tasks, limits, q, tg):
     with L.options(staged=0):
         general = DeviceProblem(dm, tasks, limits)
-    assert not general.staged
+    assert not general.staged and not general.staged_rows
     return general.solve(q, tg, DT, DAMPING), general
 
 
@@ -98,7 +98,7 @@ def test_lane_rows_stage_on_gripper_arm(env, groups, expect_left):
     B = 6144
     q, tg = inputs(model, dm, B, 21)
     staged = DeviceProblem(dm, tasks, limits)
-    assert staged.staged and staged.n_chain == 5
+    assert staged.staged and staged.staged_rows and staged.n_chain == 5
     v_s, st_s = staged.solve(q, tg, DT, DAMPING)
     (v_g, st_g), general = solve_general(dm, tasks, limits, q, tg)
     assert int(st_g.abs().sum()) == 0, torch.unique(st_g)

@@ -45,7 +45,7 @@ def main(tag, name, solves_per_launch, iterations=50):
     res = {"tag": tag, "kernel": KERNEL + "<10>", "solves_per_launch": solves_per_launch,
            "kernel_source_sha256": kernel_source_hash()}
     meta = code_object_meta.collect()      # from build/obj/*.o: the binary the run loaded was linked from these
-    res["code_object"] = {k: v for k, v in meta.items() if k.startswith(KERNEL + "<10>")}
+    res["code_object"] = {k: v for k, v in meta.items() if k.startswith(KERNEL + "<10")}
     stats = glob.glob(os.path.join(src, "kt", "**", "*_kernel_stats.csv"), recursive=True)
     rows = list(csv.DictReader(open(stats[0])))
     lines = ["| kernel | calls | avg ns | total % |", "|---|---|---|---|"]
