@@ -407,7 +407,7 @@ def other_workloads(model, dm, prob, q0, targets, out, device, barrier):
         "max_abs_dq_vs_f64_after_the_loop": float((qf[-1] - q64).abs().max().item()),
         "max_abs_d_err_norm_vs_f64": float((e32.norm(dim=1) - out["err"].norm(dim=1)).abs().max().item()),
         "stated_bound": "single step: |v_f32 - v_f64| <= 1e-3 max(1, |v|_inf) rad/s for problems with a Levenberg-Marquardt "
-                        "term on the frame task (every caller of the reference sets lm_damping = 1); measured 1.6e-4 on this "
+                        "term on the frame task at damping >= 1e-3 (every caller of the reference sets lm_damping = 1, damping 1e-3); measured 1.6e-4 on this "
                         "workload (tools/soak_f32.py, tests/test_gpu_f32.py)"}
     return extra
 

@@ -327,8 +327,9 @@ int mk_lie_op_shape(int32_t op, int32_t* wa, int32_t* wb, int32_t* wo);
  *   "f32"             0 (default): float64 arithmetic.  1: mk_solve_ik_batch, mk_solve_ik_iterate_batch and
  *                     mk_move_to_batch run the lane-per-problem kernels of the fused path in float32
  *                     arithmetic (arrays stay float64).  Bound for problems whose frame task has
- *                     lm_damping = 1: |v - v_f64|_inf <= 1e-3 max(1, |v|_inf) rad/s per step (measured
- *                     1.6e-4 on the TidyBot workload); otherwise the error grows like 1e-7 times the
+ *                     lm_damping = 1 at damping >= 1e-3 (the callers' values): |v - v_f64|_inf <=
+ *                     1e-3 max(1, |v|_inf) rad/s per step (measured 1.6e-4 on the TidyBot workload, 3.3e-4
+ *                     worst over random parameter sets); otherwise the error grows like 1e-7 times the
  *                     condition number of the Hessian, and a factorisation that loses a pivot to rounding
  *                     gives status 3 with zero velocity.  Problems outside the fused path, or with
  *                     collision limits or a relative frame task, are refused (MK_ERR_UNSUPPORTED) while

@@ -4,8 +4,8 @@ mink.solve_ik (mink/solve_ik.py:68-105) and of the callers' loop
 (interactive_scripts/teleop_mouse.py:105-121).
 
 Stated bound of the mode, for problems with a Levenberg-Marquardt term on the frame task
-(lm_damping = 1, what every caller of the reference sets: teleop_mouse.py:61-69,
-envs/mj_env.py:140-147) at any damping:
+(lm_damping = 1 at damping >= 1e-3, what every caller of the reference sets: teleop_mouse.py:61-69,
+envs/mj_env.py:140-147; the bench workload below keeps it down to damping 1e-12):
 
     one step:  |v_f32 - v_f64|_inf <= 1e-3 * max(1, |v_f64|_inf)  rad/s
     the loop:  the frame-task error reached differs by <= 2e-5 (norm), q by <= 2e-3

@@ -109,7 +109,8 @@ def main():
         label = (f"{trial} {name} gain {p['frame_gain']:.2f} lm {p['frame_lm']:.0e} posture {p['posture_cost'][3]:.0e} "
                  f"{'near' if p['near'] else 'far'}")
         r = compare(prob, dm, model, q0, tg, p["dt"], p["damping"], label, max_iters=10)
-        key = ("frame task with lm_damping = 1 (what the callers of the reference set)" if p["frame_lm"] >= 1.0
+        key = ("frame task with lm_damping = 1 and damping >= 1e-3 (what the callers of the reference set)"
+               if p["frame_lm"] >= 1.0 and p["damping"] >= 1e-3
                else "other sets (error grows with the condition number of the Hessian)")
         worst[key] = [max(a, b) for a, b in zip(worst.get(key, [0, 0, 0, 0]), r)]
     for k, w in worst.items():
