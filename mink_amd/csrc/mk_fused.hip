@@ -1813,8 +1813,10 @@ __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restric
   real qc[NC], x[NC];
 #pragma unroll
   for (int k = 0; k < NC; ++k) { qc[k] = 0.0; x[k] = 0.0; }
-  Q4 Qg = Q4{1, 0, 0, 0}, Qt = Q4{1, 0, 0, 0};
-  V3 pg = v3(0, 0, 0), pt = v3(0, 0, 0);
+  // (the goal pose is read again at every outer step instead of being held: fourteen registers
+  // less across the solver, which is what kept this kernel's spills in scratch memory)
+  Q4 Qt = Q4{1, 0, 0, 0};
+  V3 pt = v3(0, 0, 0);
   int status = 0, steps = 0, solves = 0, it = 0;
   uint32_t act = 0u, upper = 0u;
   for (;;) {
@@ -1835,9 +1837,6 @@ __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restric
         if (mine < last) {
           pid = mine;
           lane_copy(row, q + pid * nq, nq);
-          const double* gp = goals + pid * 7;
-          Qg = Q4{gp[0], gp[1], gp[2], gp[3]};
-          pg = v3(gp[4], gp[5], gp[6]);
           load_chain_q<NC>(D, row, qc);
           input_bad = rest_nonfinite(D, row);
           status = 0; steps = 0; solves = 0; it = 0;
@@ -1888,6 +1887,9 @@ __global__ MK_KERNEL_ATTR void fused_move_to_kernel(const MkFusedDesc* __restric
       if (begin) {
         // the next outer step opens on the same pose: waypoint generator, then the error
         // towards the new command
+        const double* gp = goals + pid * 7;
+        const Q4 Qg = Q4{gp[0], gp[1], gp[2], gp[3]};
+        const V3 pg = v3(gp[4], gp[5], gp[6]);
         now = waypoint_step(Q, t, Qg, pg, wp_pos_thr, wp_pos_step, wp_rot_thr, Qt, pt);
         it = 0;
         in_step = true;
