@@ -217,7 +217,8 @@ int mk_move_to_batch(const mk_problem* problem, double* d_q, const double* d_goa
  * launched and the call lasts accordingly; nothing is allocated and nothing synchronises.
  * `task_index` names the driven task (an MK_TASK_FRAME of the problem).  d_targets [B,
  * target_stride] holds the targets of the other tasks and is working memory for the driven one
- * (its slot is overwritten with the commanded pose of each step).  d_steps, d_reached, d_solves,
+ * (its slot is overwritten with the commanded pose of each step; on return it holds the pose
+ * commanded in the rollout's last step).  d_steps, d_reached, d_solves,
  * d_status [B] as above but required; d_v [B, nv], d_iters [B], d_err [B, 6] hold the state of the
  * loop and end as after the last step's mk_solve_ik_iterate_batch.
  * Replaces the loop of envs/mj_env.py:212-230 around envs/mj_env.py:266-276 for such problems. */

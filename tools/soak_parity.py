@@ -24,6 +24,12 @@ from oracle import c_oracle as co
 
 TRIALS = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+# third argument: "lane" / "coop" pins the kernel form of the fused path (default: the library's
+# choice, which is the cooperative form up to 16384 problems per call)
+FORM = sys.argv[3] if len(sys.argv) > 3 else "default"
+if FORM != "default":
+    L.set_option("coop", 1 if FORM == "coop" else 0)
+    L.set_option("handoff", 0 if FORM == "lane" else -1)
 THREADS = min(16, len(os.sched_getaffinity(0)))
 dev = "cuda:0"
 models = {n: load_builtin(n) for n in ("tidybot_cube", "mobile_kinova", "tidybot_open")}
@@ -74,7 +80,7 @@ def specs(model, p):
 
 def main():
     assert co.available(), "build the C oracle first (python -c 'import __graft_entry__ as g; g.build()')"
-    print(f"# soak: fused kernels against the C restatement, {TRIALS} random parameter sets x {B} problems\n")
+    print(f"# soak: fused kernels ({FORM} kernel form) against the C restatement, {TRIALS} random parameter sets x {B} problems\n")
     print("| # | model | dt | damping | frame gain / lm | posture | damping task | vel limit | cfg gain | targets | "
           "max abs dv (1 step) | rel. | max abs v | max abs dq (<= 10-step loop) | rel. | solve counts differ | status differ | general kernels vs fused: rel. dv | status differ |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
