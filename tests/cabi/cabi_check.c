@@ -5,7 +5,9 @@
  *      (P, c, G, h) of mk_build_qp_batch + mk_qp_solve_batch agree on the velocity,
  *   2. mk_fk_batch / mk_integrate_batch / mk_solve_ik_iterate_batch run and reduce the
  *      frame-task error,
- *   3. error returns carry a message.
+ *   3. waypoint rollouts outside the fused path (mk_move_to_passes_batch) and the process-wide
+ *      options work from C,
+ *   4. error returns carry a message.
  * Exit code 0 on success; prints what failed otherwise. */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -180,11 +182,55 @@ int main(void) {
       if (iters[b] != 5 || st[b] != 0) { printf("general loop, problem %d: %d iterations, status %d\n", b, iters[b], st[b]); return 8; }
     }
     if (closer2 < B * 8 / 10) { printf("general loop: only %d of %d problems approached their target\n", closer2, B); return 8; }
+    /* waypoint rollouts of the same problem (outside the fused path) as queued passes: goals = the
+     * frame-task targets; every rollout takes at least one step and its solves are counted */
+    {
+      static int32_t steps[B], reached[B], solves[B];
+      int32_t *d_steps = to_device(NULL, sizeof(steps)), *d_reached = to_device(NULL, sizeof(reached)),
+              *d_solves = to_device(NULL, sizeof(solves));
+      const mk_waypoint_config wp = {0.01, 0.08, 0.05, 0.3};
+      CHECK_HIP(hipMemcpy(d_q, q, sizeof(q), hipMemcpyHostToDevice));
+      if (mk_move_to_passes_batch(gen, 1, d_q, d_tg, d_tg2, &wp, dt, damping, B, 3, 4, 1e-4, 1e-4, d_steps, d_reached,
+                                  d_solves, d_st, d_v, d_it, d_err, stream) != MK_ERR_INVALID) {
+        printf("a posture task was accepted as the driven frame task\n");
+        return 9;
+      }
+      CHECK_MK(mk_move_to_passes_batch(gen, 0, d_q, d_tg, d_tg2, &wp, dt, damping, B, 3, 4, 1e-4, 1e-4, d_steps, d_reached,
+                                       d_solves, d_st, d_v, d_it, d_err, stream));
+      CHECK_HIP(hipStreamSynchronize(stream));
+      CHECK_HIP(hipMemcpy(steps, d_steps, sizeof(steps), hipMemcpyDeviceToHost));
+      CHECK_HIP(hipMemcpy(reached, d_reached, sizeof(reached), hipMemcpyDeviceToHost));
+      CHECK_HIP(hipMemcpy(solves, d_solves, sizeof(solves), hipMemcpyDeviceToHost));
+      CHECK_HIP(hipMemcpy(st, d_st, sizeof(st), hipMemcpyDeviceToHost));
+      for (int b = 0; b < B; ++b) {
+        if (steps[b] < 1 || steps[b] > 3 || solves[b] < steps[b] || solves[b] > 4 * steps[b] || st[b] != 0 ||
+            (reached[b] != 0 && reached[b] != 1)) {
+          printf("rollout %d: %d steps, %d solves, reached %d, status %d\n", b, steps[b], solves[b], reached[b], st[b]);
+          return 9;
+        }
+      }
+      (void)hipFree(d_steps); (void)hipFree(d_reached); (void)hipFree(d_solves);
+    }
     mk_problem_destroy(gen);
     (void)hipFree(d_tg2);
   }
 
-  /* 3. errors are reported, not thrown */
+  /* process-wide options: round trip, unknown names, and the float32 switch refusing what has no such kernels */
+  {
+    int64_t v0 = 0, v1 = 0;
+    CHECK_MK(mk_get_option("coop_max_batch", &v0));
+    CHECK_MK(mk_set_option("coop_max_batch", 123));
+    CHECK_MK(mk_get_option("coop_max_batch", &v1));
+    CHECK_MK(mk_set_option("coop_max_batch", v0));
+    if (v0 <= 0 || v1 != 123) { printf("option round trip: %lld -> %lld\n", (long long)v0, (long long)v1); return 10; }
+    if (mk_set_option("no_such_option", 1) != MK_ERR_INVALID) { printf("an unknown option was accepted\n"); return 10; }
+    CHECK_MK(mk_set_option("f32", 1));
+    CHECK_MK(mk_solve_ik_batch(prob, d_q, d_tg, dt, damping, B, d_v, d_st, stream));   /* fused: float32 kernels exist */
+    CHECK_MK(mk_set_option("f32", 0));
+    CHECK_HIP(hipStreamSynchronize(stream));
+  }
+
+  /* 4. errors are reported, not thrown */
   if (mk_solve_ik_batch(prob, d_q, NULL, dt, damping, B, d_v, d_st, stream) != MK_ERR_INVALID || strlen(mk_last_error()) == 0) {
     printf("missing targets were not rejected\n");
     return 7;
