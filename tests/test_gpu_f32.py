@@ -167,3 +167,19 @@ def test_lost_pivot_is_reported_not_answered(env):
     # mode does not cover such problems)
     assert set(np.unique(st).tolist()) <= {0, 1, 3} and (st == 3).mean() > 0.02
     assert not v[st == 3].any()
+
+
+@pytest.mark.parametrize("B", [1, 3, 65])
+def test_ragged_batch_sizes(env, B):
+    """Blocks with fewer than 64 problems, single problems: same answers as the same rows inside a
+    larger batch (the arithmetic of a problem does not depend on its company), bit for bit."""
+    from mink_amd.engine import DeviceProblem
+    model, dm = env
+    rng = np.random.default_rng(11)
+    q = W.sample_q(model, rng, 128)
+    tg = dm.frame_pose(dev(W.sample_q(model, rng, 128)), 2, model.site_id("pinch_site"))
+    prob = DeviceProblem(dm, W.task_specs(model, False), W.limit_specs(model, True))
+    with L.options(f32=1):
+        v_all, st_all = prob.solve(dev(q), tg, W.DT, W.DAMPING)
+        v, st = prob.solve(dev(q[:B]), tg[:B].contiguous(), W.DT, W.DAMPING)
+    assert torch.equal(v, v_all[:B]) and torch.equal(st, st_all[:B])

@@ -294,3 +294,38 @@ def test_move_to_tail_handoff_matches_lane_kernel():
     dq = (cfg_a.q - cfg_b.q).abs().amax(dim=1)[same]
     assert float(dq.max()) <= 1e-7
     assert int(a["solves"].max()) > 3 * float(a["solves"].double().mean())     # there is a tail to hand off
+
+
+@pytest.mark.gpu
+def test_move_to_passes_degenerate_counts():
+    """No outer step, no IK iteration per step, and an empty batch through mk_move_to_passes_batch:
+    the counters follow the reference's loops (envs/mj_env.py:212-230: a rollout whose generator
+    reports the goal reached stops after that step, the others run out of steps)."""
+    import mink_amd as mink
+    from mink_amd._problems import get_problem
+    from mink_amd.lie import SE3
+    B = 40
+    model, q0, frame, rel, posture, limits = _config4_rollout_inputs(B, 31)
+    cfg = mink.Configuration(model, q0)
+    start = cfg.get_transform_frame_to_world("pinch_site", "site")
+    rng = np.random.default_rng(32)
+    goal_pos = start.translation() + torch.tensor(rng.uniform(-0.2, 0.2, (B, 3)), device="cuda:0")
+    goal_pos[:10] = start.translation()[:10] + 0.002
+    goal_rot = start.rotation()
+    frame.set_target(start)
+    prob, targets = get_problem(cfg, [frame, rel, posture], limits)
+    goals = SE3.from_rotation_and_translation(goal_rot, goal_pos).wxyz_xyz.contiguous()
+    q_before = cfg.q_tensor.clone()
+    r = prob.move_to_passes_(0, cfg.q_tensor, goals, targets.clone(), CFG, 1 / 200, 1e-3, 0, 20, 1e-4, 1e-4)
+    assert int(r["steps"].abs().sum()) == 0 and int(r["reached"].sum()) == 0 and int(r["solves"].sum()) == 0
+    assert torch.equal(cfg.q_tensor, q_before)
+    r = prob.move_to_passes_(0, cfg.q_tensor, goals, targets.clone(), CFG, 1 / 200, 1e-3, 5, 0, 1e-4, 1e-4)
+    assert torch.equal(cfg.q_tensor, q_before) and int(r["solves"].sum()) == 0
+    assert r["steps"][:10].tolist() == [1] * 10 and bool(r["reached"][:10].all())
+    assert r["steps"][10:].tolist() == [5] * (B - 10) and not bool(r["reached"][10:].any())
+    empty = torch.empty((0, model.nq), dtype=torch.float64, device="cuda:0")
+    r = prob.move_to_passes_(0, empty, goals[:0].contiguous(), targets[:0].contiguous().clone(), CFG, 1 / 200, 1e-3, 5, 5,
+                             1e-4, 1e-4)
+    assert r["steps"].numel() == 0
+    with pytest.raises(mink._lib.MinkAmdError, match="frame task"):
+        prob.move_to_passes_(2, cfg.q_tensor, goals, targets.clone(), CFG, 1 / 200, 1e-3, 5, 5, 1e-4, 1e-4)
