@@ -87,7 +87,7 @@ MK_DEV bool box_box_axis(int k, V3 d, const M3& r1, V3 h1, const M3& r2, V3 h2, 
   else ax = cross(col(r1, (k - 6) / 3), col(r2, (k - 6) % 3));
   const double n2 = dot(ax, ax);
   if (!(n2 >= 1e-12)) return false;
-  ax = (1.0 / sqrt(n2)) * ax;
+  ax = mk_rsqrt(n2) * ax;          // (seed + two Newton steps: a full-precision division here was a third of the axis test)
   const V3 a1 = mulT(r1, ax), a2 = mulT(r2, ax);
   const double ra = fabs(a1.x) * h1.x + fabs(a1.y) * h1.y + fabs(a1.z) * h1.z;
   const double rb = fabs(a2.x) * h2.x + fabs(a2.y) * h2.y + fabs(a2.z) * h2.z;
