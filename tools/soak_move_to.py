@@ -18,6 +18,16 @@ from mink_amd.lie import SO3
 
 SETS = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+# third argument: "lane" / "coop" pins the kernel form of both sides.  Left to the library, the one
+# launch and the step-by-step loop hand different rollouts to the cooperative kernels at different
+# moments; the two forms agree to rounding, and a rollout whose own dynamics amplify the last bits
+# (tools/sens_move_to.py) then ends elsewhere -- the comparison is only sharp with the form pinned.
+FORM = sys.argv[3] if len(sys.argv) > 3 else "default"
+if FORM != "default":
+    from mink_amd import _lib as L
+    L.set_option("coop", 1 if FORM == "coop" else 0)
+    L.set_option("handoff", 0)
+print(f"# one-launch waypoint reaching against the step-by-step loop, kernel form: {FORM}\n")
 bad = 0
 worst = 0.0
 for k in range(SETS):
