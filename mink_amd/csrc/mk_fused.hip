@@ -852,10 +852,11 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
 // ---- general rows in the lane-per-problem form ------------------------------------------
 // CollisionAvoidanceLimit rows of one lane's problem: row k over all nv dofs, element
 // (k, dof) at g[(k * nv + dof) * stride] (the lane's LDS column on the GPU), bound h[k].
+template <int M>
 struct LaneRows {
   real* g;
   int stride, nv, n;
-  real h[MK_LANE_ROWS];
+  real h[M];
   MK_DEV real& at(int k, int dof) const { return g[(k * nv + dof) * stride]; }
 };
 
@@ -887,10 +888,10 @@ MK_DEV PoseQT coll_body_pose(const MkFusedDesc* __restrict__ D, const MkFusedExt
 // mink/limits/collision_avoidance_limit.py:83-110).  On the chain dofs the body-frame Jacobian of
 // the task frame (J, still unweighted; task frame at (tw, Rw)) gives the motion of every point
 // behind a joint: n' Rw (v_j + w_j x r) = (Rw'n).v_j + (r x Rw'n).w_j with r = Rw'(point - tw).
-template <int NC>
+template <int NC, int M>
 MK_DEV void add_point_row(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const real* row,
                           const real (&J)[6][NC], V3 tw, const M3& Rw, PoseQT tip, int b, V3 point, V3 n, real s,
-                          const LaneRows& R, int m) {
+                          const LaneRows<M>& R, int m) {
   const MkCollBody& CB = X->cbody[b];
   if (CB.kind == MK_CB_TIP) {
     // (a joint moves every point behind it the same way whichever link the point is on, so the
@@ -932,9 +933,9 @@ MK_DEV void add_point_row(const MkFusedDesc* __restrict__ D, const MkFusedExt* _
 // J is the unweighted body-frame Jacobian of the task frame at (Qw, tw, Rw).  Returns false when
 // the lane form cannot hold the problem: more than MK_LANE_ROWS rows in range, or a pair without a
 // closed form (ellipsoid, cylinder, mesh) that may be in range.
-template <int NC>
+template <int NC, int M>
 MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const real* row,
-                           const real (&J)[6][NC], Q4 Qw, V3 tw, const M3& Rw, real dt, LaneRows& R) {
+                           const real (&J)[6][NC], Q4 Qw, V3 tw, const M3& Rw, real dt, LaneRows<M>& R) {
   const Q4 postq = Q4{D->post_quat[0], D->post_quat[1], D->post_quat[2], D->post_quat[3]};
   PoseQT tip;
   tip.q = qmul(Qw, qconj(postq));
@@ -980,17 +981,17 @@ MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* 
     const bool active = geom_distance_lane(G1.type, a.t, R1, v3(G1.size[0], G1.size[1], G1.size[2]), G2.type, b.t,
                                            q2m(b.q), s2, P.d_detect, ct);
     if (!active) continue;
-    if (R.n >= MK_LANE_ROWS) { ok = false; continue; }
+    if (R.n >= M) { ok = false; continue; }
     const int m = R.n++;
     const V3 dn = ct.p2 - ct.p1;
     const real nn = sqrt(dot(dn, dn));
     const V3 nrm = nn < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nn) * dn;
     const real hval = ct.dist > P.d_min ? P.gain * (ct.dist - P.d_min) / dt + P.relax : P.relax;
 #pragma unroll
-    for (int i = 0; i < MK_LANE_ROWS; ++i)
+    for (int i = 0; i < M; ++i)
       if (i == m) R.h[i] = hval;
-    add_point_row<NC>(D, X, row, J, tw, Rw, tip, G2.body, ct.p2, nrm, -1.0, R, m);
-    add_point_row<NC>(D, X, row, J, tw, Rw, tip, G1.body, ct.p1, nrm, 1.0, R, m);
+    add_point_row<NC, M>(D, X, row, J, tw, Rw, tip, G2.body, ct.p2, nrm, -1.0, R, m);
+    add_point_row<NC, M>(D, X, row, J, tw, Rw, tip, G1.body, ct.p1, nrm, 1.0, R, m);
   }
   return ok;
 }
@@ -1013,11 +1014,10 @@ MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* 
 // multipliers).  Termination is not guaranteed: the caller hands a problem that does not finish
 // in kOuter steps to the general kernel.
 // Returns true with x (chain dofs) and the other dofs' dq in vrow[dof] (already divided by dt).
-template <int NC>
+template <int NC, int M>
 MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const real* row, HView H, const real (&c)[NC],
                     const real (&lo)[NC], const real (&hi)[NC], real diag, real dt, real inv_dt,
-                    const LaneRows& R, real (&x)[NC], real* vrow) {
-  constexpr int M = MK_LANE_ROWS;
+                    const LaneRows<M>& R, real (&x)[NC], real* vrow) {
   constexpr int kOuter = 16;
   constexpr real kTol = 1e-13;
   real mu[M], mu_prev[M], merit_prev = INFINITY;
@@ -1313,7 +1313,7 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const real* row, HView H,
 // within range, QP assembly and the solve with those rows.  q is the problem's row of the batch
 // (read in place), hstore / gstore the lane's columns for H and the rows.  Returns true when
 // vrow [nv] holds the problem's velocity; false leaves the problem to the general kernel.
-template <int NC>
+template <int NC, int M = MK_LANE_ROWS>
 MK_DEV bool rows_problem(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const real* row,
                          const real* tg_row, real dt, real inv_dt, real damping, real* vrow, real* hstore,
                          int hstride, real* gstore, int gstride) {
@@ -1328,15 +1328,17 @@ MK_DEV bool rows_problem(const MkFusedDesc* __restrict__ D, const MkFusedExt* __
   M3 Rw;
   chain_jac_pose<NC, true>(D, qc, cj, Qw, tw, Rw, X->has_rel ? X->rel_slot : NC, &Qcap, &tcap);
   cj.e = frame_error(Qw, tw, Rw, Qt, pt);
-  LaneRows R;
+  LaneRows<M> R;
   R.g = gstore;
   R.stride = gstride;
   R.nv = D->nv;
   R.n = 0;
 #pragma unroll
-  for (int k = 0; k < MK_LANE_ROWS; ++k) R.h[k] = INFINITY;
-  for (int i = 0; i < MK_LANE_ROWS * D->nv; ++i) gstore[i * gstride] = 0.0;
-  const bool fits = collision_rows<NC>(D, X, row, cj.J, Qw, tw, Rw, dt, R);
+  for (int k = 0; k < M; ++k) R.h[k] = INFINITY;
+  for (int i = 0; i < M * D->nv; ++i) gstore[i * gstride] = 0.0;
+  const bool fits = collision_rows<NC, M>(D, X, row, cj.J, Qw, tw, Rw, dt, R);
+  // (a wave none of whose problems fits this many rows leaves them all to the next stage at once)
+  if (mk_wave_none(fits)) return false;
   real c[NC], lo[NC], hi[NC], hacc = 0.0, diag;
   if (X->has_rel) {
     const real* tr = tg_row + X->rel_target_off;
@@ -1353,7 +1355,7 @@ MK_DEV bool rows_problem(const MkFusedDesc* __restrict__ D, const MkFusedExt* __
                                         Twist{V3{0, 0, 0}, V3{0, 0, 0}}, hacc);
   }
   asm volatile("" ::: "memory");
-  bool good = rows_qp<NC>(D, row, HView{hstore, hstride}, c, lo, hi, diag, dt, inv_dt, R, x, vrow);
+  bool good = rows_qp<NC, M>(D, row, HView{hstore, hstride}, c, lo, hi, diag, dt, inv_dt, R, x, vrow);
   good &= fits && (diag > 0.0);
   if (good) {
 #pragma unroll
@@ -1368,7 +1370,7 @@ MK_DEV bool rows_problem(const MkFusedDesc* __restrict__ D, const MkFusedExt* __
 // status array in chunks of 64 entries (chunk c belongs to block c mod gridDim.x), queues the
 // pending indices in LDS and works through the queue 64 problems at a time.  A problem it
 // finishes gets its velocity row and status 0; one it cannot finish stays pending.
-template <int NC>
+template <int NC, int M>
 __global__ MK_KERNEL_ATTR void fused_rows_kernel(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X,
                                                  const double* __restrict__ q, const double* __restrict__ targets,
                                                  int target_stride, real dt, real damping, int B,
@@ -1379,7 +1381,7 @@ __global__ MK_KERNEL_ATTR void fused_rows_kernel(const MkFusedDesc* __restrict__
   const int lane = threadIdx.x;
   real* hlds = tile + lane;
   real* glds = tile + NH * 64 + lane;
-  int32_t* queue = reinterpret_cast<int32_t*>(tile + (NH + MK_LANE_ROWS * nv) * 64);   // 128 entries
+  int32_t* queue = reinterpret_cast<int32_t*>(tile + (NH + M * nv) * 64);   // 128 entries
   const real inv_dt = 1.0 / dt;
   const int nchunks = (B + 63) / 64;
   int n = 0;
@@ -1398,7 +1400,7 @@ __global__ MK_KERNEL_ATTR void fused_rows_kernel(const MkFusedDesc* __restrict__
       const bool valid = lane < take;
       const long pb = queue[valid ? lane : 0];
       // lanes without a problem of their own repeat the first one, stores included (same values)
-      const bool good = rows_problem<NC>(D, X, q + pb * nq, targets + pb * target_stride, dt, inv_dt, damping,
+      const bool good = rows_problem<NC, M>(D, X, q + pb * nq, targets + pb * target_stride, dt, inv_dt, damping,
                                          v_out + pb * nv, hlds, 64, glds, 64);
       if (valid && good) status_out[pb] &= ~MK_STATUS_PENDING;   // the low bits: status accumulated by a loop
       const int rest = n - take;
@@ -2039,21 +2041,38 @@ hipError_t mk_fused_launch_step_ext(int nc, const MkFusedDesc* d_desc, const MkF
   }
 }
 
+// One launch of the rows stage for problems with at most M rows in range.
+template <int NC, int M>
+static hipError_t launch_rows_m(const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nv, const double* q,
+                                const double* targets, int target_stride, double dt, double damping, int B, double* v,
+                                int32_t* status, hipStream_t stream) {
+  // per wave: H and the general rows of 64 problems, and the queue of pending indices
+  const size_t lds = (size_t)64 * (NC * (NC + 1) / 2 + M * nv) * sizeof(real) + 128 * sizeof(int32_t);
+  // a model too wide for one wave's rows to fit the LDS of a compute unit skips this stage: its
+  // pending problems all go to the general kernel
+  if (lds > (size_t)160 * 1024) return hipSuccess;
+  if (hipError_t e = allow_lds<fused_rows_kernel<NC, M>>(lds); e != hipSuccess) return e;
+  // as many resident waves per compute unit as the LDS allows (at most one per SIMD); each scans
+  // its chunks of the status array
+  const int per_cu = std::max(1, std::min(4, (int)(((size_t)160 * 1024) / lds)));
+  const int blocks = std::max(1, std::min((B + 63) / 64, wave_slots() / 4 * per_cu));
+  hipLaunchKernelGGL((fused_rows_kernel<NC, M>), dim3(blocks), dim3(64), lds, stream, d_desc, d_ext, q, targets,
+                     target_stride, dt, damping, B, v, status);
+  return hipGetLastError();
+}
+
+// The rows stage in two launches: problems with at most two rows in range first -- half the LDS
+// per wave (three resident waves per compute unit instead of two for TidyBot), a 2 x 2 instead of
+// a 4 x 4 complementarity problem per step and far fewer registers -- then, for what that leaves
+// pending, the form with MK_LANE_ROWS rows.
 template <int NC>
 static hipError_t launch_rows(const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nv, const double* q,
                               const double* targets, int target_stride, double dt, double damping, int B, double* v,
                               int32_t* status, hipStream_t stream) {
-  // per wave: H and the general rows of 64 problems, and the queue of pending indices
-  const size_t lds = (size_t)64 * (NC * (NC + 1) / 2 + MK_LANE_ROWS * nv) * sizeof(real) + 128 * sizeof(int32_t);
-  // a model too wide for one wave's rows to fit the LDS of a compute unit skips this stage: its
-  // pending problems all go to the general kernel
-  if (lds > (size_t)160 * 1024) return hipSuccess;
-  if (hipError_t e = allow_lds<fused_rows_kernel<NC>>(lds); e != hipSuccess) return e;
-  // two resident waves per compute unit at this LDS size; each scans its chunks of the status array
-  const int blocks = std::max(1, std::min((B + 63) / 64, wave_slots() / 2));
-  hipLaunchKernelGGL(fused_rows_kernel<NC>, dim3(blocks), dim3(64), lds, stream, d_desc, d_ext, q, targets,
-                     target_stride, dt, damping, B, v, status);
-  return hipGetLastError();
+  if (hipError_t e = launch_rows_m<NC, 2>(d_desc, d_ext, nv, q, targets, target_stride, dt, damping, B, v, status, stream);
+      e != hipSuccess)
+    return e;
+  return launch_rows_m<NC, MK_LANE_ROWS>(d_desc, d_ext, nv, q, targets, target_stride, dt, damping, B, v, status, stream);
 }
 
 hipError_t mk_fused_launch_rows(int nc, const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nv, const double* q,
