@@ -359,6 +359,15 @@ def other_workloads(model, dm, prob, q0, targets, out, device, barrier):
         wg, eg = time_launches(lambda i: p4.iterate_(qg[i], tl, W.DT, W.DAMPING, 20, -1.0, -1.0, out=out4), 1, 1, barrier)
     loop4["general_kernel_passes"] = {"solves_per_s": Bl * 20 / wg, "ms_per_loop": 1e3 * eg}
     loop4["max_abs_q_diff"] = float((ql[2] - qg[1]).abs().max().item())
+    loop4["note"] = ("rows [0, 65536) of the config-4 batch are its near-contact quarter: every problem of this loop has a "
+                     "collision pair in range in every pass; staged_passes_mixed runs the same loop on a batch with the "
+                     "single-step workload's mix (a quarter near contact)")
+    qm4, tm4 = W.config4_inputs(model, dm, Bl, SEED + 1)
+    qm = [qm4.clone() for _ in range(3)]
+    wm, em = time_launches(lambda i: p4.iterate_(qm[i], tm4, W.DT, W.DAMPING, 20, -1.0, -1.0, out=out4), 2, 1, barrier)
+    loop4["staged_passes_mixed"] = {"solves_per_s": Bl * 20 * 2 / wm, "ms_per_loop": 1e3 * em / 2,
+                                    "status_nonzero": int((out4["status"] != 0).sum().item())}
+    del qm4, tm4, qm
     extra["config4_loop_B65536_x20"] = loop4
     del q4, tg4, v4, s4, ql, qg
     # kinematic move_to rollouts (waypoint generator + the callers' IK loop per waypoint step) as one launch
