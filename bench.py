@@ -290,8 +290,8 @@ def other_workloads(model, dm, prob, q0, targets, out, device, barrier):
         stats_n, ms_per_launch=1e3 * en / NSTEP_N, solves_per_s=Bn * stats_n["mean_solves"] * NSTEP_N / wn,
         solves_per_s_by_launch_duration=Bn * stats_n["mean_solves"] * NSTEP_N / en,
         problems_per_s=Bn * NSTEP_N / wn, lane_kernel_alone_ms_per_launch=1e3 * el_ / NSTEP_N,
-        kernels="fused_iterate_kernel<10, hand-off> then coop_resume_kernel<10>: a wave of the lane kernel stops when "
-                "4 or fewer of its problems are left and the cooperative kernel finishes those",
+        kernels="fused_iterate_kernel<10, hand-off>, one launch: a wave leaves the lane-per-problem loop when 4 or "
+                "fewer of its problems are left and finishes those at 16 lanes per problem",
         note="offset targets (<= 0.17 m, <= 0.52 rad), FrameTask + PostureTask, default ConfigurationLimit, "
              "<= 20 iterations with the 1e-4 / 1e-4 exit test (interactive_scripts/teleop_mouse.py:105-121); "
              "solves counted as executed")

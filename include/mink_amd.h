@@ -340,8 +340,9 @@ int mk_lie_op_shape(int32_t op, int32_t* wa, int32_t* wb, int32_t* wo);
  *                     interactive_scripts/teleop_mouse.py:99-125); 0 never; 1 always
  *   "coop_max_batch"  default 16384
  *   "handoff"         -1 (default): in a loop with an exit test on more problems than that, a wave of the
- *                     lane-per-problem kernel hands its last 4 problems still in the loop to the
- *                     cooperative kernel (a second launch on the same stream); 0 never; n > 0 its last n
+ *                     lane-per-problem kernel finishes its last 4 problems still in the loop in the
+ *                     cooperative form (within the launch; the streaming and rollout kernels in a
+ *                     second launch on the same stream); 0 never; n > 0 its last n
  *   "stream_blocks"   -1 (default): lane streaming of the iterated entry by batch size; 0 never;
  *                     n > 0 always, with n persistent waves
  *   "stream_refill"   default 16: waiting lanes before the streaming kernels hand out problems

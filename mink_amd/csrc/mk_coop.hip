@@ -22,6 +22,8 @@
 //
 // Every function here is device code; tests/hostsim builds the same source for the host with
 // the row operations emulated by 16 cooperating fibers (MK_COOP_HOSTSIM).
+#ifndef MK_COOP_FUNCS_INCLUDED
+#define MK_COOP_FUNCS_INCLUDED
 #include "mk_device.h"
 
 #include <type_traits>
@@ -1036,7 +1038,15 @@ MK_CO void coop_move_to_body(const MkFusedDesc* __restrict__ D, double* __restri
   }
 }
 
-#if !defined(MK_COOP_NO_KERNELS)
+}  // namespace
+#endif  // MK_COOP_FUNCS_INCLUDED
+
+// The device functions above are also compiled into mk_fused.hip (whose loop kernel finishes
+// the problems it hands off with coop_iterate_body), which includes this file with
+// MK_COOP_NO_KERNELS defined; the kernels and launchers below belong to this file's own object.
+#if !defined(MK_COOP_NO_KERNELS) && !defined(MK_COOP_KERNELS_INCLUDED)
+#define MK_COOP_KERNELS_INCLUDED
+namespace {
 template <int NC>
 __global__ __launch_bounds__(64) void coop_step_kernel(const MkFusedDesc* __restrict__ D, const double* __restrict__ q,
                                                        const double* __restrict__ targets, int target_stride, double dt,
@@ -1137,11 +1147,9 @@ __global__ __launch_bounds__(64) void coop_resume_kernel(const MkFusedDesc* __re
     }
   }
 }
-#endif
 
 }  // namespace
 
-#if !defined(MK_COOP_NO_KERNELS)
 // ---- host-side launchers (called from mk_api.hip) ----
 hipError_t mk_coop_launch_step(int nc, const MkFusedDesc* d_desc, const double* q, const double* targets,
                                int target_stride, double dt, double damping, int B, double* v, int32_t* status,

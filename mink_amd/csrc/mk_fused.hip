@@ -28,6 +28,11 @@
 #include "mk_generic.h"
 #if !defined(MK_F32)
 #include "mk_geom.h"
+// the cooperative device functions (one problem per 16-lane row): the loop kernel with a
+// hand-off finishes its last problems with them
+#define MK_COOP_NO_KERNELS
+#include "mk_coop.hip"
+#undef MK_COOP_NO_KERNELS
 #endif
 #include "mk_options.h"
 
@@ -1518,8 +1523,10 @@ __global__ MK_KERNEL_ATTR void fused_step_ext_kernel(const MkFusedDesc* __restri
 // HANDOFF: a wave whose problems have all but `handoff_live` of them left the loop stops there and
 // marks the rest (MK_ITER_CONT_BIT in iters_out, which must be given): with the exit test the
 // problems of a wave finish at different iterations, and the last few would hold the launch for
-// their remaining sequential solves; the cooperative kernel (coop_resume_kernel, mk_coop.hip)
-// finishes them at 16 lanes per problem.
+// their remaining sequential solves; the cooperative form (coop_iterate_body, mk_coop.hip)
+// finishes them at 16 lanes per problem -- in this same launch (the wave takes its own marked
+// problems, four at a time, one per 16-lane row, once its rows are back in memory); the
+// streaming and rollout kernels leave theirs to coop_resume_kernel / coop_move_to_resume_kernel.
 #endif  // !MK_F32
 
 template <int NC, bool HANDOFF = false>
@@ -1623,6 +1630,28 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
   }
   __syncthreads();
   tile_copy<false>(tile, stride, q + base * nq, rows, nq);
+#if !defined(MK_F32)
+  if constexpr (HANDOFF) {
+    uint64_t marked = __ballot(valid && handed);   // wave-uniform; at most handoff_live bits
+    if (marked != 0ull) {
+      // the rows, counters and statuses written above are read back by other lanes of this wave
+      __threadfence();
+      __syncthreads();
+      while (marked != 0ull) {   // four problems at a time, one per 16-lane row
+        uint64_t m = marked;
+        for (int k = 0; k < (lane >> 4); ++k) m &= m - 1ull;
+        if (m != 0ull) {
+          const long pr = base + (__ffsll((unsigned long long)m) - 1);
+          const int it0 = iters_out[pr] & ~MK_ITER_CONT_BIT;
+          coop_iterate_body<NC>(D_arg, q, targets, target_stride, (double)dt, (double)damping, max_iters,
+                                (double)pos_tol, (double)ori_tol, v_out, iters_out, err_out, status_out, pr, true, it0,
+                                status_out[pr]);
+        }
+        for (int k = 0; k < 4 && marked != 0ull; ++k) marked &= marked - 1ull;
+      }
+    }
+  }
+#endif
 }
 
 // Per-lane copy of n doubles with the loads of eight elements in flight together (a plain
@@ -2089,9 +2118,9 @@ hipError_t mk_fused_launch_rows(int nc, const MkFusedDesc* d_desc, const MkFused
 
 #endif  // !MK_F32
 
-// handoff_live > 0 (and an exit test, and `iters` given): the block-per-64 kernel may leave up to
-// that many problems per wave marked MK_ITER_CONT_BIT for mk_coop_launch_resume; *handed tells
-// whether this launch was of that kind.
+// handoff_live > 0 (and an exit test, and `iters` given): the kernels may leave up to that many
+// problems per wave marked MK_ITER_CONT_BIT for mk_coop_launch_resume; *handed tells whether
+// this launch can have left any.
 hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, double* q, const double* targets,
                                    int target_stride, double dt, double damping, int B, int max_iters,
                                    double pos_tol, double ori_tol, double* v, int32_t* iters, double* err,
@@ -2121,6 +2150,8 @@ hipError_t mk_fused_launch_iterate(int nc, const MkFusedDesc* d_desc, int nq, do
       default: return hipErrorInvalidValue;
     }
   }
+  // (the block-per-64 kernel finishes its marked problems itself)
+  if (handed) *handed = false;
   switch (nc) {
 #define MK_CASE(N)                                                                                         \
   case N:                                                                                                  \

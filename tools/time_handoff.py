@@ -38,7 +38,7 @@ for B in [int(a) for a in sys.argv[1:]] or [32768, 65536, 98304]:
                status=torch.empty(B, dtype=torch.int32, device=dev))
     qs = [q0[:B].clone() for _ in range(34)]
     line = []
-    for h in (0, 1, 2, 4, 8, 16, 32, 64):
+    for h in (0, 2, 4, 6, 8, 12, 16, 24, 32):
         with L.options(handoff=h, coop_max_batch=0):
             for qq in qs:
                 qq.copy_(q0[:B])
