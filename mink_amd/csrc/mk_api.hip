@@ -1135,9 +1135,11 @@ int mk_problem_create(const mk_model* model, const mk_task_desc* tasks, int32_t 
     p->allocs.push_back(d);
   }
   if (p->staged && !p->dense) p->staged = false, p->info.staged = 0;   // the second stage is the general kernel
-  // (the LDS the rows kernel asks for, as in its launcher in mk_fused.hip: H and MK_LANE_ROWS rows of 64 problems)
-  p->info.staged_rows = (p->staged && (size_t)64 * (p->nc_kernel * (p->nc_kernel + 1) / 2 + MK_LANE_ROWS * m.nv) * sizeof(double) +
-                                          128 * sizeof(int32_t) <= (size_t)160 * 1024) ? 1 : 0;
+  // (as in the rows kernel's launcher in mk_fused.hip: a lane holds rows of up to MK_ROWS_MAX_NV dofs, and the form
+  // for MK_LANE_ROWS rows keeps H and the rows of 64 problems in LDS)
+  p->info.staged_rows = (p->staged && m.nv <= MK_ROWS_MAX_NV &&
+                         (size_t)64 * (p->nc_kernel * (p->nc_kernel + 1) / 2 + MK_LANE_ROWS * m.nv) * sizeof(double) +
+                                 128 * sizeof(int32_t) <= (size_t)160 * 1024) ? 1 : 0;
   if (!p->fused && !p->dense) {
     std::string msg = "no kernel path serves this problem: fused: " + why + "; dense: " + p->dense_why;
     mk_problem_destroy(p);

@@ -101,6 +101,7 @@ struct MkFusedDesc {
 // keeps, a pair without a closed form -- ellipsoid, cylinder, mesh --, no convergence of its dual
 // iteration).
 constexpr int MK_LANE_ROWS = 4;    // general rows per problem in the lane-per-problem solve
+constexpr int MK_ROWS_MAX_NV = 48; // dofs of a model whose general rows the lane-per-problem solve holds
 constexpr int MK_MAX_CBODY = 10;    // bodies carrying collision geoms
 constexpr int MK_MAX_CSEG = 4;     // 1-dof joints between the chain and such a body
 constexpr int MK_MAX_CGEOM = 24;

@@ -855,14 +855,32 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
 }
 
 // ---- general rows in the lane-per-problem form ------------------------------------------
-// CollisionAvoidanceLimit rows of one lane's problem: row k over all nv dofs, element
-// (k, dof) at g[(k * nv + dof) * stride] (the lane's LDS column on the GPU), bound h[k].
+// CollisionAvoidanceLimit rows of one lane's problem, bound h[k]: row k over all nv dofs, element
+// (k, dof) at g[(k * nv + dof) * stride].  With at most two rows the entries at the chain's dofs
+// are kept apart, slot i of the chain (dof seg_dof[i]) at gc[(k * ncs + i) * cstride]: the solve
+// reads the chain part in every sweep, and the kernel then gives it the faster memory.
 template <int M>
 struct LaneRows {
+  static constexpr bool kSplit = M <= 2;
   real* g;
-  int stride, nv, n;
+  real* gc;
+  const int* seg_dof;
+  int stride, cstride, nv, ncs, n;
   real h[M];
   MK_DEV real& at(int k, int dof) const { return g[(k * nv + dof) * stride]; }
+  // entry of row k at chain slot i (zero for a slot without a dof)
+  MK_DEV real chain(int k, int i) const {
+    if constexpr (kSplit) {
+      return gc[(k * ncs + i) * cstride];
+    } else {
+      const int dof = seg_dof[i];
+      return dof >= 0 ? g[(k * nv + dof) * stride] : real(0.0);
+    }
+  }
+  MK_DEV void chain_add(int k, int i, real val) const {   // (slot i has a dof)
+    if constexpr (kSplit) gc[(k * ncs + i) * cstride] += val;
+    else g[(k * nv + seg_dof[i]) * stride] += val;
+  }
 };
 
 // World pose of collision body b; `tip` is the frame behind the chain's last joint.
@@ -907,7 +925,7 @@ MK_DEV void add_point_row(const MkFusedDesc* __restrict__ D, const MkFusedExt* _
     for (int j = 0; j < NC; ++j) {
       const int dof = D->seg_dof[j];
       const real val = nt.x * J[0][j] + nt.y * J[1][j] + nt.z * J[2][j] + mt.x * J[3][j] + mt.y * J[4][j] + mt.z * J[5][j];
-      if (dof >= 0 && j <= CB.slot) R.at(m, dof) += s * val;
+      if (dof >= 0 && j <= CB.slot) R.chain_add(m, j, s * val);
     }
     PoseQT f = CB.slot >= D->nc - 1 ? tip : chain_frame_pose(D, row, CB.slot);
     for (int sidx = 0; sidx < CB.nseg; ++sidx) {
@@ -934,7 +952,7 @@ MK_DEV void add_point_row(const MkFusedDesc* __restrict__ D, const MkFusedExt* _
 
 // Rows of the CollisionAvoidanceLimit pairs of one problem that are within their detection
 // distance (mink/limits/collision_avoidance_limit.py:187-210): G[k] = -n'(Jp2 - Jp1),
-// h[k] = gain (dist - d_min) / dt + relax (relax at dist <= d_min).  R.g must be zero on entry.
+// h[k] = gain (dist - d_min) / dt + relax (relax at dist <= d_min).  R.g and R.gc must be zero on entry.
 // J is the unweighted body-frame Jacobian of the task frame at (Qw, tw, Rw).  Returns false when
 // the lane form cannot hold the problem: more than MK_LANE_ROWS rows in range, or a pair without a
 // closed form (ellipsoid, cylinder, mesh) that may be in range.
@@ -1038,11 +1056,10 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const real* row, HView H,
       real cm[NC];
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
-        const int dof = D->seg_dof[i];
         real sft = 0.0;
 #pragma unroll
-        for (int k = 0; k < M; ++k) sft += mu[k] * R.at(k, dof >= 0 ? dof : 0);
-        cm[i] = c[i] + (dof >= 0 ? sft : 0.0);
+        for (int k = 0; k < M; ++k) sft += mu[k] * R.chain(k, i);
+        cm[i] = c[i] + sft;
       }
       asm volatile("" ::: "memory");
       const int st = box_qp<NC>(H, cm, lo, hi, x, act, upper, it > 0);
@@ -1051,12 +1068,12 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const real* row, HView H,
       for (int k = 0; k < M; ++k) r[k] = k < nrows ? -R.h[k] : 0.0;
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
-        const int dof = D->seg_dof[i];
 #pragma unroll
-        for (int k = 0; k < M; ++k) r[k] += (dof >= 0 ? R.at(k, dof) : 0.0) * x[i];
+        for (int k = 0; k < M; ++k) r[k] += R.chain(k, i) * x[i];
       }
       uint64_t clamped = 0ull;
       bool infeasible = st != 0;
+#pragma unroll 4
       for (int d = 0; d < nd; ++d) {
         const MkDofC dc = D->ddof[d];
         const real qi = row[dc.qadr];
@@ -1075,6 +1092,7 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const real* row, HView H,
         vrow[dc.dof] = y * inv_dt;
       }
       for (int f = 0; f < D->nfree; ++f) {
+#pragma unroll
         for (int j = 0; j < 6; ++j) {
           const int dof = D->free_dofadr[f] + j;
           real g[M], sft = 0.0;
@@ -1126,20 +1144,17 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const real* row, HView H,
         for (int k = 0; k < M; ++k) {
           real sk[NC];
 #pragma unroll
-          for (int i = 0; i < NC; ++i) {
-            const int dof = D->seg_dof[i];
-            sk[i] = (dof >= 0 && !((act >> i) & 1u)) ? R.at(k, dof) : 0.0;
-          }
+          for (int i = 0; i < NC; ++i) sk[i] = ((act >> i) & 1u) ? 0.0 : R.chain(k, i);
           chol_solve<NC>(L, Ld, sk);
 #pragma unroll
           for (int i = 0; i < NC; ++i) {
-            const int dof = D->seg_dof[i];
-            const bool fr = dof >= 0 && !((act >> i) & 1u);
+            const bool fr = !((act >> i) & 1u);
 #pragma unroll
             for (int l = 0; l < M; ++l)
-              if (l >= k) S[k][l] += (fr ? R.at(l, dof) : 0.0) * sk[i];
+              if (l >= k) S[k][l] += (fr ? R.chain(l, i) : 0.0) * sk[i];
           }
         }
+#pragma unroll 4
         for (int d = 0; d < nd; ++d) {
           const MkDofC dc = D->ddof[d];
           const real iw = ((clamped >> d) & 1ull) ? 0.0 : mk_rcp(diag + dc.W);
@@ -1153,6 +1168,7 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const real* row, HView H,
               if (l >= k) S[k][l] += g[k] * g[l] * iw;
         }
         for (int f = 0; f < D->nfree; ++f) {
+#pragma unroll
           for (int j = 0; j < 6; ++j) {
             const int dof = D->free_dofadr[f] + j;
             real g[M];
@@ -1270,8 +1286,7 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const real* row, HView H,
             real tau = INFINITY;
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
-              const int dof = D->seg_dof[i];
-              const real gki = dof >= 0 ? R.at(k, dof) : 0.0;
+              const real gki = R.chain(k, i);
               const bool up = (upper >> i) & 1u;
               const real gi = cm[i] + hx[i];
               const real ui = fmax(up ? -gi : gi, 0.0), slope = up ? -gki : gki;
@@ -1316,12 +1331,13 @@ MK_DEV bool rows_qp(const MkFusedDesc* __restrict__ D, const real* row, HView H,
 
 // One pending problem of the staged solve in the lane form: chain kinematics, the collision rows
 // within range, QP assembly and the solve with those rows.  q is the problem's row of the batch
-// (read in place), hstore / gstore the lane's columns for H and the rows.  Returns true when
+// (read in place), hstore / gstore the lane's storage for H and the rows (M * nv elements), cstore
+// that of the rows' chain part where it is kept apart (M * NC elements, M <= 2).  Returns true when
 // vrow [nv] holds the problem's velocity; false leaves the problem to the general kernel.
 template <int NC, int M = MK_LANE_ROWS>
 MK_DEV bool rows_problem(const MkFusedDesc* __restrict__ D, const MkFusedExt* __restrict__ X, const real* row,
                          const real* tg_row, real dt, real inv_dt, real damping, real* vrow, real* hstore,
-                         int hstride, real* gstore, int gstride) {
+                         int hstride, real* cstore, int cstride, real* gstore, int gstride) {
   const real* tg = tg_row + D->target_off;
   const Q4 Qt = Q4{tg[0], tg[1], tg[2], tg[3]};
   const V3 pt = v3(tg[4], tg[5], tg[6]);
@@ -1336,11 +1352,19 @@ MK_DEV bool rows_problem(const MkFusedDesc* __restrict__ D, const MkFusedExt* __
   LaneRows<M> R;
   R.g = gstore;
   R.stride = gstride;
+  R.gc = cstore;
+  R.cstride = cstride;
+  R.seg_dof = D->seg_dof;
   R.nv = D->nv;
+  R.ncs = NC;
   R.n = 0;
 #pragma unroll
   for (int k = 0; k < M; ++k) R.h[k] = INFINITY;
   for (int i = 0; i < M * D->nv; ++i) gstore[i * gstride] = 0.0;
+  if constexpr (LaneRows<M>::kSplit) {
+#pragma unroll
+    for (int i = 0; i < M * NC; ++i) cstore[i * cstride] = 0.0;
+  }
   const bool fits = collision_rows<NC, M>(D, X, row, cj.J, Qw, tw, Rw, dt, R);
   // (a wave none of whose problems fits this many rows leaves them all to the next stage at once)
   if (mk_wave_none(fits)) return false;
@@ -1385,8 +1409,19 @@ __global__ MK_KERNEL_ATTR void fused_rows_kernel(const MkFusedDesc* __restrict__
   const int nq = D->nq, nv = D->nv;
   const int lane = threadIdx.x;
   real* hlds = tile + lane;
-  real* glds = tile + NH * 64 + lane;
-  int32_t* queue = reinterpret_cast<int32_t*>(tile + (NH + M * nv) * 64);   // 128 entries
+  // The form for at most two rows keeps only their chain part in LDS and the entries at the
+  // other dofs in the lane's private memory: H and the chain part of two rows are 38 KB per wave
+  // for a ten-joint chain, which lets every SIMD of a compute unit hold a wave, where H and two
+  // whole rows of a 24-dof model (53 KB) allow three -- and the pending problems of a large batch
+  // then take two rounds of batches instead of one.  The private entries are read in sweeps over
+  // the dofs, all lanes at the same element, which the private segment's lane-interleaved layout
+  // serves as contiguous lines.  The form for more rows, which few problems need, has them in LDS.
+  constexpr bool kSplit = LaneRows<M>::kSplit;
+  real gpriv[kSplit ? M * MK_ROWS_MAX_NV : 1];
+  real* cstore = tile + NH * 64 + lane;
+  real* gstore = kSplit ? gpriv : tile + NH * 64 + lane;
+  const int gstride = kSplit ? 1 : 64;
+  int32_t* queue = reinterpret_cast<int32_t*>(tile + (NH + (kSplit ? M * NC : M * nv)) * 64);   // 128 entries
   const real inv_dt = 1.0 / dt;
   const int nchunks = (B + 63) / 64;
   int n = 0;
@@ -1406,7 +1441,7 @@ __global__ MK_KERNEL_ATTR void fused_rows_kernel(const MkFusedDesc* __restrict__
       const long pb = queue[valid ? lane : 0];
       // lanes without a problem of their own repeat the first one, stores included (same values)
       const bool good = rows_problem<NC, M>(D, X, q + pb * nq, targets + pb * target_stride, dt, inv_dt, damping,
-                                         v_out + pb * nv, hlds, 64, glds, 64);
+                                         v_out + pb * nv, hlds, 64, cstore, 64, gstore, gstride);
       if (valid && good) status_out[pb] &= ~MK_STATUS_PENDING;   // the low bits: status accumulated by a loop
       const int rest = n - take;
       const int32_t mv = lane < rest ? queue[64 + lane] : 0;
@@ -2075,11 +2110,11 @@ template <int NC, int M>
 static hipError_t launch_rows_m(const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nv, const double* q,
                                 const double* targets, int target_stride, double dt, double damping, int B, double* v,
                                 int32_t* status, hipStream_t stream) {
-  // per wave: H and the general rows of 64 problems, and the queue of pending indices
-  const size_t lds = (size_t)64 * (NC * (NC + 1) / 2 + M * nv) * sizeof(real) + 128 * sizeof(int32_t);
-  // a model too wide for one wave's rows to fit the LDS of a compute unit skips this stage: its
-  // pending problems all go to the general kernel
-  if (lds > (size_t)160 * 1024) return hipSuccess;
+  // per wave: H and the rows (the chain part of up to two rows) of 64 problems and the queue of pending indices
+  const size_t lds = (size_t)64 * (NC * (NC + 1) / 2 + (M <= 2 ? M * NC : M * nv)) * sizeof(real) + 128 * sizeof(int32_t);
+  // a model with more dofs than a lane's private rows hold, or too wide for one wave's rows to fit
+  // the LDS of a compute unit, skips this stage: its pending problems all go to the general kernel
+  if (nv > MK_ROWS_MAX_NV || lds > (size_t)160 * 1024) return hipSuccess;
   if (hipError_t e = allow_lds<fused_rows_kernel<NC, M>>(lds); e != hipSuccess) return e;
   // as many resident waves per compute unit as the LDS allows (at most one per SIMD); each scans
   // its chunks of the status array
@@ -2090,10 +2125,9 @@ static hipError_t launch_rows_m(const MkFusedDesc* d_desc, const MkFusedExt* d_e
   return hipGetLastError();
 }
 
-// The rows stage in two launches: problems with at most two rows in range first -- half the LDS
-// per wave (three resident waves per compute unit instead of two for TidyBot), a 2 x 2 instead of
-// a 4 x 4 complementarity problem per step and far fewer registers -- then, for what that leaves
-// pending, the form with MK_LANE_ROWS rows.
+// The rows stage in two launches: problems with at most two rows in range first -- a 2 x 2 instead
+// of a 4 x 4 complementarity problem per step and far fewer registers -- then, for what that
+// leaves pending, the form with MK_LANE_ROWS rows.
 template <int NC>
 static hipError_t launch_rows(const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nv, const double* q,
                               const double* targets, int target_stride, double dt, double damping, int B, double* v,

@@ -156,13 +156,15 @@ int run_rows(const MkFusedDesc& D, const MkFusedExt& X, const double* q, const d
              double damping, int B, double* v, int32_t* good, int32_t* nrows) {
   double hbuf[MK_MAX_CHAIN * (MK_MAX_CHAIN + 1) / 2];
   std::vector<double> gbuf((size_t)MK_LANE_ROWS * D.nv);
+  double cbuf[MK_LANE_ROWS * NC] = {};   // (written only by the forms that keep the chain part apart)
   for (int b = 0; b < B; ++b) {
     good[b] = rows_problem<NC>(&D, &X, q + (size_t)b * D.nq, targets + (size_t)b * stride, dt, 1.0 / dt, damping,
-                               v + (size_t)b * D.nv, hbuf, 1, gbuf.data(), 1) ? 1 : 0;
+                               v + (size_t)b * D.nv, hbuf, 1, cbuf, 1, gbuf.data(), 1) ? 1 : 0;
     int n = 0;
     for (int k = 0; k < MK_LANE_ROWS; ++k) {
       bool any = false;
       for (int i = 0; i < D.nv; ++i) any |= gbuf[(size_t)k * D.nv + i] != 0.0;
+      for (int i = 0; i < NC; ++i) any |= cbuf[k * NC + i] != 0.0;
       n += any;
     }
     if (nrows) nrows[b] = n;
