@@ -1269,7 +1269,7 @@ int mk_solve_ik_batch(const mk_problem* p, const double* d_q, const double* d_ta
                                     dt, damping, B, d_v, d_status, static_cast<hipStream_t>(stream),
                                     3 * p->h_ext.ncgeom + 4 * p->h_ext.norient));
     const bool lane_rows = mk_opt(MK_OPT_LANE_ROWS) != 0;   // tuning / tests: skip the middle stage
-    if (p->h_ext.ncpair > 0 && lane_rows)
+    if (p->h_ext.ncpair > 0 && lane_rows && p->info.staged_rows)
       MK_HIP(mk_fused_launch_rows(p->nc_kernel, p->d_fused, p->d_ext, p->info.nv, d_q, d_targets, p->info.target_stride,
                                   dt, damping, B, d_v, d_status, static_cast<hipStream_t>(stream)));
     // diagnostic switch of the tests: without the last stage, the problems it would have solved
@@ -1318,7 +1318,8 @@ static int iterate_passes(const mk_problem* p, double* d_q, const double* d_targ
                                       d_err, it, max_iters, pos_tol, ori_tol));
       if (it == max_iters) break;
       if (p->h_ext.ncpair > 0) {
-        MK_HIP(mk_fused_launch_rows(p->nc_kernel, p->d_fused, p->d_ext, p->info.nv, d_q, d_targets, p->info.target_stride, dt,
+        if (p->info.staged_rows)
+          MK_HIP(mk_fused_launch_rows(p->nc_kernel, p->d_fused, p->d_ext, p->info.nv, d_q, d_targets, p->info.target_stride, dt,
                                     damping, B, d_v, d_status, st));
         MK_HIP(mk_dense_launch(p->model->dev, p->d_dense, p->info.n_rows, p->h_dense.n_general, d_q, d_targets,
                                p->info.target_stride, dt, damping, B, nullptr, nullptr, nullptr, nullptr, d_v, d_status, -1,

@@ -720,6 +720,27 @@ __global__ MK_KERNEL_ATTR void fused_step_kernel(const MkFusedDesc* __restrict__
   tile_copy<false>(tile, stride, v_out + base * nv, rows, nv);
 }
 
+// Per-lane copy of n doubles with the loads of eight elements in flight together (a plain
+// loop waits for every element's round trip in turn; nothing else hides that latency at one
+// wave per SIMD).
+template <typename TD, typename TS>
+MK_DEV void lane_copy(TD* __restrict__ dst, const TS* __restrict__ src, int n) {
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    TS t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = src[i + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[i + k] = (TD)t[k];
+  }
+  TS t[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) t[k] = (i + k < n) ? src[i + k] : TS(0.0);
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (i + k < n) dst[i + k] = (TD)t[k];
+}
+
 #if !defined(MK_F32)
 // Pose composition helpers of the collision screen.
 struct PoseQT {
@@ -997,6 +1018,9 @@ MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* 
       lower = sqrt(dot(d, d)) - G1.rbound - G2.rbound;
     }
     if (lower >= P.d_detect) continue;
+#if defined(MK_ROWS_ABLATE) && MK_ROWS_ABLATE == 1
+    continue;   // tuning build only: no exact distances, so no rows
+#endif
     const bool closed1 = G1.type == 0 || G1.type == 2 || G1.type == 3 || G1.type == 6;
     const bool closed2 = G2.type == 2 || G2.type == 3 || G2.type == 6;
     if (!closed1 || !closed2) { ok = false; continue; }   // support-mapping pair: the general kernel
@@ -1004,6 +1028,11 @@ MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* 
     const bool active = geom_distance_lane(G1.type, a.t, R1, v3(G1.size[0], G1.size[1], G1.size[2]), G2.type, b.t,
                                            q2m(b.q), s2, P.d_detect, ct);
     if (!active) continue;
+#if defined(MK_ROWS_ABLATE) && MK_ROWS_ABLATE == 2
+    // tuning build only: the exact distances are computed and dropped
+    asm volatile("" ::"v"(ct.dist), "v"(ct.p1.x), "v"(ct.p1.y), "v"(ct.p1.z), "v"(ct.p2.x), "v"(ct.p2.y), "v"(ct.p2.z));
+    continue;
+#endif
     if (R.n >= M) { ok = false; continue; }
     const int m = R.n++;
     const V3 dn = ct.p2 - ct.p1;
@@ -1687,27 +1716,6 @@ __global__ MK_KERNEL_ATTR void fused_iterate_kernel(const MkFusedDesc* __restric
     }
   }
 #endif
-}
-
-// Per-lane copy of n doubles with the loads of eight elements in flight together (a plain
-// loop waits for every element's round trip in turn; nothing else hides that latency at one
-// wave per SIMD).
-template <typename TD, typename TS>
-MK_DEV void lane_copy(TD* __restrict__ dst, const TS* __restrict__ src, int n) {
-  int i = 0;
-  for (; i + 8 <= n; i += 8) {
-    TS t[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t[k] = src[i + k];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) dst[i + k] = (TD)t[k];
-  }
-  TS t[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) t[k] = (i + k < n) ? src[i + k] : TS(0.0);
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-    if (i + k < n) dst[i + k] = (TD)t[k];
 }
 
 // The callers' loop for batches much larger than the machine, with early exit: a persistent
