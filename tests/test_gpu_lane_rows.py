@@ -323,3 +323,36 @@ def test_staged_solve_with_mesh_geoms_on_tidybot_arm_links():
     assert int(in_range.sum()) > B // 10
     assert bool(left[in_range].all())            # the screen never drops a problem with a row in range
     assert int((~left).sum()) > B // 10          # and it does spare the general kernel a share of the batch
+
+
+def test_model_wider_than_the_lane_rows_skips_the_rows_stage(tmp_path):
+    """The rows stage holds rows of models up to a fixed number of dofs; a wider model (here the
+    gripper arm with four more free bodies, nv 55) stays a staged problem whose pending problems
+    all go to the general kernel, with the same answers."""
+    xml = open(os.path.join(HERE, "models", "grip_arm.xml")).read()
+    extra = "".join(f'    <body name="extra{i}" pos="{0.5 + 0.1 * i} 0.5 0.3">\n      <freejoint name="extra{i}_free"/>\n'
+                    f'      <geom name="extra{i}_geom" type="sphere" size="0.02" mass="0.05"/>\n    </body>\n' for i in range(4))
+    assert xml.count("  </worldbody>") == 1
+    path = tmp_path / "grip_arm_wide.xml"
+    path.write_text(xml.replace("  </worldbody>", extra + "  </worldbody>"))
+    model = load_mjcf(str(path))
+    assert model.nv == 55
+    dm = DeviceModel(model, torch.device("cuda:0"))
+    groups = [(["pad_a", "pad_b"], ["brick_geom", "floor", "pillar"]), (["tip_b"], ["ball_geom", "floor"])]
+    tasks, limits = specs(model, groups)
+    B = 2048
+    q, tg = inputs(model, dm, B, 33)
+    staged = DeviceProblem(dm, tasks, limits)
+    assert staged.staged and not staged.staged_rows
+    v_s, st_s = staged.solve(q, tg, DT, DAMPING)
+    (v_g, st_g), _ = solve_general(dm, tasks, limits, q, tg)
+    assert int(st_g.abs().sum()) == 0 and torch.equal(st_s, st_g)
+    assert float((v_s - v_g).abs().max()) <= 1e-9
+    # and through the callers' loop (passes of the structured and the general kernel only)
+    qa, qb = q.clone(), q.clone()
+    r_s = staged.iterate_(qa, tg, DT, DAMPING, 5, 1e-4, 1e-4)
+    with L.options(staged=0):
+        general = DeviceProblem(dm, tasks, limits)
+    r_g = general.iterate_(qb, tg, DT, DAMPING, 5, 1e-4, 1e-4)
+    assert torch.equal(r_s["iters"], r_g["iters"]) and torch.equal(r_s["status"], r_g["status"])
+    assert float((qa - qb).abs().max()) <= 1e-8
