@@ -615,11 +615,21 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
         S.slide = 1.0 - S.hinge;
         S.qadr = m.jnt_qposadr[j];
         S.dof = m.jnt_dofadr[j];
+        // (coarse screen: the fixed offset in front of the joint, and the travel of a slide joint)
+        if (CB.reach >= 0.0) {
+          CB.reach += std::sqrt(S.pp[0] * S.pp[0] + S.pp[1] * S.pp[1] + S.pp[2] * S.pp[2]);
+          if (jt == MK_JNT_SLIDE) {
+            if (m.jnt_limited[j]) CB.reach += std::max(std::fabs(m.jnt_range[2 * j]), std::fabs(m.jnt_range[2 * j + 1]));
+            else CB.reach = -1.0;
+          }
+        }
       }
     }
     if (CB.kind == MK_CB_FREE && CB.nseg > 0) { why = "joints below a free body"; return -1; }
     memcpy(CB.tp, pp, sizeof(pp));
     memcpy(CB.tq, pq, sizeof(pq));
+    if (CB.kind == MK_CB_WORLD) CB.reach = 0.0;   // (tp is its world position: the geoms' centres are taken as they are)
+    else if (CB.reach >= 0.0) CB.reach += std::sqrt(pp[0] * pp[0] + pp[1] * pp[1] + pp[2] * pp[2]);
     X->cbody[X->ncbody] = CB;
     return body_slot[gb] = X->ncbody++;
   };
@@ -694,6 +704,32 @@ bool build_fused(const HostModel& m, const mk_task_desc* tasks, int ntask, const
   for (int k = 0; k < X->ncpair; ++k) {
     X->cpair[k].g1 = where[X->cpair[k].g1];
     X->cpair[k].g2 = where[X->cpair[k].g2];
+  }
+  // coarse bounds of the screen (see MkCollGeom)
+  for (int g = 0; g < X->ncgeom; ++g) {
+    MkCollGeom& G = X->cgeom[g];
+    const MkCollBody& CB = X->cbody[G.body];
+    const double off = std::sqrt(G.lp[0] * G.lp[0] + G.lp[1] * G.lp[1] + G.lp[2] * G.lp[2]) +
+                       std::sqrt(G.bc[0] * G.bc[0] + G.bc[1] * G.bc[1] + G.bc[2] * G.bc[2]);
+    G.wc[0] = G.wc[1] = G.wc[2] = 0.0;
+    G.wn[0] = G.wn[1] = 0.0;
+    G.wn[2] = 1.0;
+    if (CB.kind == MK_CB_WORLD) {
+      double wp[3], wq[4];
+      memcpy(wp, CB.tp, sizeof(wp));
+      memcpy(wq, CB.tq, sizeof(wq));
+      compose(wp, wq, G.lp, G.lq);
+      double c[3];
+      const double ez[3] = {0.0, 0.0, 1.0};
+      hq_rotate(wq, G.bc, c);
+      for (int i = 0; i < 3; ++i) G.wc[i] = wp[i] + c[i];
+      hq_rotate(wq, ez, G.wn);
+      G.reach = G.rbound;
+    } else if (G.type == 0 || CB.reach < 0.0 || (CB.kind == MK_CB_TIP && CB.slot < D.nc - 1)) {
+      G.reach = -1.0;
+    } else {
+      G.reach = CB.reach + off + G.rbound;
+    }
   }
   return true;
 }

@@ -124,7 +124,8 @@ struct MkCollBody {
   int32_t g0, ng;         // its geoms: cgeom[g0 .. g0 + ng)
   MkCollSeg seg[MK_MAX_CSEG];
   double tq[4], tp[3];    // fixed transform behind the last joint (WORLD: the world pose)
-  double pad2;
+  double reach;           // how far the body frame's origin can get from the frame that carries the body
+                          // (the joints between them over their ranges); < 0: not bounded
 };
 struct MkCollGeom {
   int32_t body, type;     // index into cbody, MuJoCo geom type
@@ -132,6 +133,12 @@ struct MkCollGeom {
   double size[3], rbound; // rbound: radius of a bounding sphere about bc
   double bc[3];           // centre of the bounding sphere in the geom frame (meshes; 0 otherwise)
   int32_t oslot, pad;     // planes and boxes: index among the oriented geoms (-1 otherwise)
+  // coarse bound of the collision screen: every point of the geom lies within `reach` of its
+  // anchor -- the origin of the frame behind the chain's last joint (bodies carried by it), the
+  // free joint's position, or, for a geom fixed in the world, the sphere centre wc itself.
+  // reach < 0: no such bound (a body on an inner link of the chain, an unlimited slide joint, a
+  // plane that moves).  wn: the normal of a plane fixed in the world.
+  double reach, wc[3], wn[3];
 };
 struct MkCollPair {
   int32_t g1, g2;         // indices into cgeom, ordered by geom type

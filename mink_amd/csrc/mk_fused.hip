@@ -777,6 +777,41 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
   PoseQT tip;
   tip.q = qmul(Qw, qconj(postq));
   tip.t = tw - qrot(tip.q, v3(D->post_pos[0], D->post_pos[1], D->post_pos[2]));
+  const int np = X->ncpair;
+  // Coarse bounds first, from the positions the lane has already: a geom lies within G.reach of
+  // the frame that carries its body.  A wave none of whose problems has a pair inside these
+  // bounds skips the poses of the bodies and geoms below (for TidyBot, four gripper pads behind
+  // three or four finger joints each).
+  {
+    bool maybe = false;
+    auto anchor = [&](const MkCollGeom& G) -> V3 {
+      const MkCollBody& CB = X->cbody[G.body];
+      if (CB.kind == MK_CB_TIP) return tip.t;
+      if (CB.kind == MK_CB_FREE) {
+        const real* f = row + CB.free_qadr;
+        return v3(f[0], f[1], f[2]);
+      }
+      return v3(G.wc[0], G.wc[1], G.wc[2]);
+    };
+    for (int k = 0; k < np; ++k) {
+      const MkCollPair& P = X->cpair[k];
+      const MkCollGeom& G1 = X->cgeom[P.g1];
+      const MkCollGeom& G2 = X->cgeom[P.g2];
+      if (G1.reach < 0.0 || G2.reach < 0.0) {   // (the same for all lanes)
+        maybe = true;
+        continue;
+      }
+      real lower;
+      if (G1.type == 0) {
+        lower = dot(anchor(G2) - v3(G1.wc[0], G1.wc[1], G1.wc[2]), v3(G1.wn[0], G1.wn[1], G1.wn[2])) - G2.reach;
+      } else {
+        const V3 d = anchor(G2) - anchor(G1);
+        lower = sqrt(dot(d, d)) - G1.reach - G2.reach;
+      }
+      maybe |= !(lower >= P.d_detect);   // also true for a non-finite bound
+    }
+    if (mk_wave_none(maybe)) return false;
+  }
   // per geom the world centre of its bounding sphere (element 3 g + c of the lane's scratch column,
   // scr[e * ss]); behind them the orientation of the planes and boxes (4 each, by G.oslot)
   const int nb = X->ncbody, ng = X->ncgeom;
@@ -812,7 +847,6 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
     }
   }
   bool near = false;
-  const int np = X->ncpair;
   for (int k = 0; k < np; ++k) {
     const int g1 = X->cpair[k].g1, g2 = X->cpair[k].g2;
     const real d_detect = X->cpair[k].d_detect;
@@ -845,26 +879,37 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
       const V3 d = bcw - ac;
       lower = sqrt(dot(d, d)) - G1.rbound - G2.rbound;
       if (G1.type == 6 && G2.type == 6 && lower < d_detect) {
-        // two boxes: the largest gap along the 15 candidate separating axes
+        // two boxes: the largest gap along the 15 candidate separating axes, in the frame of box 1
+        // (C = R1'R2, t = R1'd: an axis u has extent sum_k |R'u|_k h_k on a box, and for the
+        // face normals and the edge cross products R1'u and R2'u are columns, rows and cross
+        // products of unit vectors with columns of C)
         const M3 R1 = q2m(a.q), R2 = q2m(b.q);
-        const V3 h1 = v3(G1.size[0], G1.size[1], G1.size[2]), h2 = v3(G2.size[0], G2.size[1], G2.size[2]);
+        const real h1[3] = {G1.size[0], G1.size[1], G1.size[2]}, h2[3] = {G2.size[0], G2.size[1], G2.size[2]};
+        real C[3][3], t[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const V3 ci = v3(R1.m[i], R1.m[3 + i], R1.m[6 + i]);
+          t[i] = dot(ci, d);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) C[i][j] = dot(ci, v3(R2.m[j], R2.m[3 + j], R2.m[6 + j]));
+        }
         real gap = -INFINITY;
 #pragma unroll
-        for (int ax = 0; ax < 15; ++ax) {
-          V3 u;
-          if (ax < 3) u = v3(R1.m[ax], R1.m[3 + ax], R1.m[6 + ax]);
-          else if (ax < 6) u = v3(R2.m[ax - 3], R2.m[ax], R2.m[ax + 3]);
-          else {
-            const int i = (ax - 6) / 3, j = (ax - 6) % 3;
-            u = cross(v3(R1.m[i], R1.m[3 + i], R1.m[6 + i]), v3(R2.m[j], R2.m[3 + j], R2.m[6 + j]));
-          }
-          const real n2 = dot(u, u);
-          if (n2 >= 1e-12) {
-            u = (1.0 / sqrt(n2)) * u;
-            const V3 a1 = mulT(R1, u), a2 = mulT(R2, u);
-            const real ra = fabs(a1.x) * h1.x + fabs(a1.y) * h1.y + fabs(a1.z) * h1.z;
-            const real rb = fabs(a2.x) * h2.x + fabs(a2.y) * h2.y + fabs(a2.z) * h2.z;
-            gap = fmax(gap, fabs(dot(d, u)) - ra - rb);
+        for (int i = 0; i < 3; ++i)   // face normals of box 1
+          gap = fmax(gap, fabs(t[i]) - h1[i] - (h2[0] * fabs(C[i][0]) + h2[1] * fabs(C[i][1]) + h2[2] * fabs(C[i][2])));
+#pragma unroll
+        for (int j = 0; j < 3; ++j)   // face normals of box 2
+          gap = fmax(gap, fabs(t[0] * C[0][j] + t[1] * C[1][j] + t[2] * C[2][j]) - h2[j] -
+                              (h1[0] * fabs(C[0][j]) + h1[1] * fabs(C[1][j]) + h1[2] * fabs(C[2][j])));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {   // edge i of box 1 x edge j of box 2; |e_i x C_j|^2 without cancellation
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            const real n2 = C[i1][j] * C[i1][j] + C[i2][j] * C[i2][j];
+            const real num = fabs(t[i2] * C[i1][j] - t[i1] * C[i2][j]) - (h1[i1] * fabs(C[i2][j]) + h1[i2] * fabs(C[i1][j])) -
+                             (h2[j1] * fabs(C[i][j2]) + h2[j2] * fabs(C[i][j1]));
+            if (n2 >= 1e-12) gap = fmax(gap, num * mk_rsqrt(n2));
           }
         }
         lower = fmax(lower, gap);
