@@ -348,6 +348,7 @@ int mk_lie_op_shape(int32_t op, int32_t* wa, int32_t* wb, int32_t* wo);
  *   "stream_refill"   default 16: waiting lanes before the streaming kernels hand out problems
  *   "staged"          0: problems with collision limits skip the staged solve (read by mk_problem_create)
  *   "lane_rows", "general_stage", "staged_loop"   0: skip that stage of the staged solve
+ *                     ("lane_rows" = 2: only the first of its two launches, the form that solves with two rows)
  *                     (diagnostic; without "general_stage" the problems it would have solved
  *                     report status 1)
  * Unknown names give MK_ERR_INVALID.  Values are read at launch time with relaxed atomics. */

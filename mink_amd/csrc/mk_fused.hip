@@ -924,7 +924,9 @@ MK_DEV bool collision_in_range(const MkFusedDesc* __restrict__ D, const MkFusedE
 // CollisionAvoidanceLimit rows of one lane's problem, bound h[k]: row k over all nv dofs, element
 // (k, dof) at g[(k * nv + dof) * stride].  With at most two rows the entries at the chain's dofs
 // are kept apart, slot i of the chain (dof seg_dof[i]) at gc[(k * ncs + i) * cstride]: the solve
-// reads the chain part in every sweep, and the kernel then gives it the faster memory.
+// reads the chain part in every sweep, and the kernel then gives it the faster memory; row k's
+// other entries are those of row idx[k] of the storage g (the rows of the problem as they were
+// built, of which the solve takes a selection).
 template <int M>
 struct LaneRows {
   static constexpr bool kSplit = M <= 2;
@@ -932,8 +934,10 @@ struct LaneRows {
   real* gc;
   const int* seg_dof;
   int stride, cstride, nv, ncs, n;
+  int nzero;   // rows [0, nzero) of the storage are zero on entry of collision_rows; it clears the others as it takes them
+  int idx[M];
   real h[M];
-  MK_DEV real& at(int k, int dof) const { return g[(k * nv + dof) * stride]; }
+  MK_DEV real& at(int k, int dof) const { return g[((kSplit ? idx[k] : k) * nv + dof) * stride]; }
   // entry of row k at chain slot i (zero for a slot without a dof)
   MK_DEV real chain(int k, int i) const {
     if constexpr (kSplit) {
@@ -1018,7 +1022,7 @@ MK_DEV void add_point_row(const MkFusedDesc* __restrict__ D, const MkFusedExt* _
 
 // Rows of the CollisionAvoidanceLimit pairs of one problem that are within their detection
 // distance (mink/limits/collision_avoidance_limit.py:187-210): G[k] = -n'(Jp2 - Jp1),
-// h[k] = gain (dist - d_min) / dt + relax (relax at dist <= d_min).  R.g and R.gc must be zero on entry.
+// h[k] = gain (dist - d_min) / dt + relax (relax at dist <= d_min).  Rows [0, R.nzero) of R.g must be zero on entry.
 // J is the unweighted body-frame Jacobian of the task frame at (Qw, tw, Rw).  Returns false when
 // the lane form cannot hold the problem: more than MK_LANE_ROWS rows in range, or a pair without a
 // closed form (ellipsoid, cylinder, mesh) that may be in range.
@@ -1080,6 +1084,8 @@ MK_DEV bool collision_rows(const MkFusedDesc* __restrict__ D, const MkFusedExt* 
 #endif
     if (R.n >= M) { ok = false; continue; }
     const int m = R.n++;
+    if (m >= R.nzero)
+      for (int dof = 0; dof < R.nv; ++dof) R.at(m, dof) = 0.0;
     const V3 dn = ct.p2 - ct.p1;
     const real nn = sqrt(dot(dn, dn));
     const V3 nrm = nn < MK_MINVAL ? v3(1, 0, 0) : (1.0 / nn) * dn;
@@ -1423,25 +1429,70 @@ MK_DEV bool rows_problem(const MkFusedDesc* __restrict__ D, const MkFusedExt* __
   M3 Rw;
   chain_jac_pose<NC, true>(D, qc, cj, Qw, tw, Rw, X->has_rel ? X->rel_slot : NC, &Qcap, &tcap);
   cj.e = frame_error(Qw, tw, Rw, Qt, pt);
-  LaneRows<M> R;
-  R.g = gstore;
-  R.stride = gstride;
-  R.gc = cstore;
-  R.cstride = cstride;
-  R.seg_dof = D->seg_dof;
-  R.nv = D->nv;
-  R.ncs = NC;
-  R.n = 0;
+  // The rows are built for up to MB pairs in range.  The form that solves with fewer (M = 2) takes
+  // the M rows with the smallest bounds -- the closest pairs -- and checks the others at its
+  // solution afterwards: a row that holds there does not change the optimum, so the answer is that
+  // of the whole problem; if one does not hold, the problem is left to the next stage.
+  constexpr bool kSplit = LaneRows<M>::kSplit;
+  constexpr int MB = kSplit ? MK_LANE_ROWS : M;
+  LaneRows<MB> RA;
+  RA.g = gstore;
+  RA.stride = gstride;
+  RA.gc = cstore;
+  RA.cstride = cstride;
+  RA.seg_dof = D->seg_dof;
+  RA.nv = D->nv;
+  RA.ncs = NC;
+  RA.n = 0;
 #pragma unroll
-  for (int k = 0; k < M; ++k) R.h[k] = INFINITY;
-  for (int i = 0; i < M * D->nv; ++i) gstore[i * gstride] = 0.0;
-  if constexpr (LaneRows<M>::kSplit) {
-#pragma unroll
-    for (int i = 0; i < M * NC; ++i) cstore[i * cstride] = 0.0;
+  for (int k = 0; k < MB; ++k) {
+    RA.h[k] = INFINITY;
+    RA.idx[k] = k;
   }
-  const bool fits = collision_rows<NC, M>(D, X, row, cj.J, Qw, tw, Rw, dt, R);
+  // (the solve reads all of its M rows, in range or not; the rows it does not read are cleared when they are taken)
+  RA.nzero = M;
+  for (int i = 0; i < M * D->nv; ++i) gstore[i * gstride] = 0.0;
+  const bool fits = collision_rows<NC, MB>(D, X, row, cj.J, Qw, tw, Rw, dt, RA);
   // (a wave none of whose problems fits this many rows leaves them all to the next stage at once)
   if (mk_wave_none(fits)) return false;
+  LaneRows<M> R;
+  if constexpr (!kSplit) {
+    R = RA;
+  } else {
+    static_assert(!kSplit || M == 2, "the selection below picks two rows");
+    R.g = gstore;
+    R.stride = gstride;
+    R.gc = cstore;
+    R.cstride = cstride;
+    R.seg_dof = D->seg_dof;
+    R.nv = D->nv;
+    R.ncs = NC;
+    R.n = min(RA.n, M);
+    int i0 = 0, i1 = 1;
+    if (RA.n > M) {
+      real h0 = INFINITY, h1 = INFINITY;
+#pragma unroll
+      for (int k = 0; k < MB; ++k) {
+        const real hk = RA.h[k];   // (INFINITY beyond the rows in range)
+        if (hk < h0) { h1 = h0; i1 = i0; h0 = hk; i0 = k; }
+        else if (hk < h1) { h1 = hk; i1 = k; }
+      }
+      if (i1 < i0) { const int t = i0; i0 = i1; i1 = t; }   // (in pair order, like a problem with two rows)
+    }
+    R.idx[0] = i0;
+    R.idx[1] = i1;
+#pragma unroll
+    for (int k = 0; k < MB; ++k) {
+      if (k == i0) R.h[0] = RA.h[k];
+      if (k == i1) R.h[1] = RA.h[k];
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int dof = D->seg_dof[i];
+      cstore[i * cstride] = dof >= 0 ? gstore[(i0 * R.nv + dof) * gstride] : real(0.0);
+      cstore[(NC + i) * cstride] = dof >= 0 ? gstore[(i1 * R.nv + dof) * gstride] : real(0.0);
+    }
+  }
   real c[NC], lo[NC], hi[NC], hacc = 0.0, diag;
   if (X->has_rel) {
     const real* tr = tg_row + X->rel_target_off;
@@ -1460,6 +1511,41 @@ MK_DEV bool rows_problem(const MkFusedDesc* __restrict__ D, const MkFusedExt* __
   asm volatile("" ::: "memory");
   bool good = rows_qp<NC, M>(D, row, HView{hstore, hstride}, c, lo, hi, diag, dt, inv_dt, R, x, vrow);
   good &= fits && (diag > 0.0);
+  if constexpr (kSplit) {
+    // the rows the solve left out, at its solution (chain dofs in x, the others as written to vrow)
+    const bool more = good && RA.n > M;
+    if (!mk_wave_none(more)) {
+      real r[MB];
+#pragma unroll
+      for (int k = 0; k < MB; ++k) {
+        r[k] = -RA.h[k];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) r[k] += RA.chain(k, i) * x[i];
+      }
+      // (dofs outside, rows inside, a few dofs at a time: the loads of a sweep are independent)
+#pragma unroll 4
+      for (int d = 0; d < D->nd; ++d) {
+        const int dof = D->ddof[d].dof;
+        const real y = vrow[dof] * dt;
+#pragma unroll
+        for (int k = 0; k < MB; ++k) r[k] += RA.at(k, dof) * y;
+      }
+      for (int f = 0; f < D->nfree; ++f) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int dof = D->free_dofadr[f] + j;
+          const real y = vrow[dof] * dt;
+#pragma unroll
+          for (int k = 0; k < MB; ++k) r[k] += RA.at(k, dof) * y;
+        }
+      }
+      bool holds = true;
+#pragma unroll
+      for (int k = 0; k < MB; ++k)
+        if (k < RA.n && k != R.idx[0] && k != R.idx[1]) holds &= r[k] <= 1e-13 * fmax(1.0, fabs(RA.h[k]));
+      if (more) good = holds;
+    }
+  }
   if (good) {
 #pragma unroll
     for (int k = 0; k < NC; ++k)
@@ -1491,7 +1577,7 @@ __global__ MK_KERNEL_ATTR void fused_rows_kernel(const MkFusedDesc* __restrict__
   // the dofs, all lanes at the same element, which the private segment's lane-interleaved layout
   // serves as contiguous lines.  The form for more rows, which few problems need, has them in LDS.
   constexpr bool kSplit = LaneRows<M>::kSplit;
-  real gpriv[kSplit ? M * MK_ROWS_MAX_NV : 1];
+  real gpriv[kSplit ? MK_LANE_ROWS * MK_ROWS_MAX_NV : 1];   // (all rows of a problem: the solve selects M of them)
   real* cstore = tile + NH * 64 + lane;
   real* gstore = kSplit ? gpriv : tile + NH * 64 + lane;
   const int gstride = kSplit ? 1 : 64;
@@ -2178,9 +2264,10 @@ static hipError_t launch_rows_m(const MkFusedDesc* d_desc, const MkFusedExt* d_e
   return hipGetLastError();
 }
 
-// The rows stage in two launches: problems with at most two rows in range first -- a 2 x 2 instead
-// of a 4 x 4 complementarity problem per step and far fewer registers -- then, for what that
-// leaves pending, the form with MK_LANE_ROWS rows.
+// The rows stage in two launches: the form that solves with two rows first -- a 2 x 2 instead of
+// a 4 x 4 complementarity problem per step and far fewer registers; it finishes the problems
+// with at most two rows in range and those with more whose two closest pairs decide the answer --
+// then, for what that leaves pending, the form with MK_LANE_ROWS rows.
 template <int NC>
 static hipError_t launch_rows(const MkFusedDesc* d_desc, const MkFusedExt* d_ext, int nv, const double* q,
                               const double* targets, int target_stride, double dt, double damping, int B, double* v,
@@ -2188,6 +2275,7 @@ static hipError_t launch_rows(const MkFusedDesc* d_desc, const MkFusedExt* d_ext
   if (hipError_t e = launch_rows_m<NC, 2>(d_desc, d_ext, nv, q, targets, target_stride, dt, damping, B, v, status, stream);
       e != hipSuccess)
     return e;
+  if (mk_opt(MK_OPT_LANE_ROWS) == 2) return hipSuccess;   // (tests: the two-row form alone)
   return launch_rows_m<NC, MK_LANE_ROWS>(d_desc, d_ext, nv, q, targets, target_stride, dt, damping, B, v, status, stream);
 }
 

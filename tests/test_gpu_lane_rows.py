@@ -356,3 +356,33 @@ def test_model_wider_than_the_lane_rows_skips_the_rows_stage(tmp_path):
     r_g = general.iterate_(qb, tg, DT, DAMPING, 5, 1e-4, 1e-4)
     assert torch.equal(r_s["iters"], r_g["iters"]) and torch.equal(r_s["status"], r_g["status"])
     assert float((qa - qb).abs().max()) <= 1e-8
+
+
+def test_two_row_form_finishes_problems_with_more_rows_in_range(env):
+    """The first launch of the rows stage solves with the two closest pairs' rows and checks the
+    other rows in range at its solution: where they hold, that is the answer of the whole problem
+    (collision_avoidance_limit.py:187-210 gives a row to every pair in range; a row that does not
+    bind does not move the optimum); where one does not, the problem is left to the next launch."""
+    model, dm = env
+    groups = [(list(HAND), list(OBJECTS) + ["floor", "pillar"])]
+    tasks, limits = specs(model, groups)
+    B = 6144
+    q, tg = inputs(model, dm, B, 77)
+    staged = DeviceProblem(dm, tasks, limits)
+    (v_g, st_g), general = solve_general(dm, tasks, limits, q, tg)
+    P, c, G, h = general.build_qp(q, tg, DT, DAMPING)
+    npair = len(limits[2]["index"]) // 2
+    in_range = torch.isfinite(h[:, -npair:]).sum(dim=1)
+    with L.options(lane_rows=2, general_stage=0):
+        v_2, st_2 = staged.solve(q, tg, DT, DAMPING)
+    done = st_2 == 0
+    many = (in_range > 2) & (in_range <= 4)
+    print("3 or 4 rows in range:", int(many.sum()), "of them finished by the two-row form:", int((many & done).sum()),
+          "; more than 4 rows finished:", int(((in_range > 4) & done).sum()))
+    assert int((many & done).sum()) > 20 and int((many & ~done).sum()) > 0
+    assert not bool(((in_range > 4) & done).any())       # more rows than the build keeps: never finished here
+    assert float((v_2[done] - v_g[done]).abs().max()) <= 1e-9
+    # the dropped rows of the finished problems hold at the answer
+    Gc, hc = G[:, -npair:], h[:, -npair:]
+    r = torch.einsum("bmn,bn->bm", Gc, v_2 * DT) - hc
+    assert float(r[done][torch.isfinite(hc[done])].max()) <= 1e-9
