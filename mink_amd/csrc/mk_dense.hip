@@ -1422,7 +1422,12 @@ hipError_t mk_dense_launch(const MkDevModel& m, const MkDenseProblem* d_problem,
   if (lds == 0) return hipErrorInvalidValue;
   static MkLdsGrant grant;
   if (hipError_t e = mk_grant_lds(reinterpret_cast<const void*>(dense_kernel), lds, grant); e != hipSuccess) return e;
-  hipLaunchKernelGGL(dense_kernel, dim3(dense_grid(B, lds)), dim3(64), lds, s, m, d_problem, n_rows, n_general, m.npath, q,
+  int grid = dense_grid(B, lds);
+  // the last stage of a staged solve usually finds little or nothing pending: no more waves than
+  // chunks of the status array to scan, and no more than the machine holds at once (a launch of
+  // 4096 waves that all leave at once costs 20 us)
+  if (only_pending) grid = std::max(1, std::min(grid, std::min((B + 63) / 64, 2048)));
+  hipLaunchKernelGGL(dense_kernel, dim3(grid), dim3(64), lds, s, m, d_problem, n_rows, n_general, m.npath, q,
                      targets, target_stride, dt, damping, B, P, c, G, h, v, status, eval_task, err, jac, skip_flags,
                      accumulate_status ? 1 : 0, only_pending ? 1 : 0);
   return hipGetLastError();
